@@ -1,0 +1,115 @@
+/* libscilmm_hip C ABI -- the drop-in boundary of the MI355X-native sparse-Cholesky REML engine.
+ *
+ * The reference has no FFI: its boundary is the duck-typed Python protocol
+ *     cholesky_func(V) -> factor ;  factor(b), factor.L(), factor.P(), factor.logdet()
+ * implemented by sksparse.cholmod (reference scilmm/SparseCholesky.py:16-26, used at :30,:32,:40,:50,
+ * :52,:93,:100; twin scilmm/Estimation/LMM.py:14-24).  Each entry point below names the reference call it
+ * replaces.  The Python shim (scilmm_amd/_lib.py, scilmm_amd/factor.py) binds exactly these symbols through
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status (0 = ok, <0 = error);
+ * opaque handles; caller-allocated outputs; int64 offsets, int32 indices, float64 values; dense
+ * right-hand sides are ROW-major n x r (NumPy C order, what the reference passes); one handle may be used
+ * from one thread at a time; no global state.  Functions suffixed _dev take DEVICE pointers (HBM) and
+ * enqueue on the handle's stream without synchronising.
+ */
+#ifndef SCILMM_HIP_H
+#define SCILMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SCILMM_OK = 0,
+  SCILMM_ERR_ARG = -1,        /* bad argument / handle */
+  SCILMM_ERR_NOT_PD = -2,     /* V is not positive definite (sksparse: CholmodNotPositiveDefiniteError) */
+  SCILMM_ERR_DEVICE = -3,     /* HIP runtime error (no device, launch failure, out of memory) */
+  SCILMM_ERR_STATE = -4       /* call order violated (e.g. factorize before values_upload) */
+};
+
+typedef struct scilmm_symbolic scilmm_symbolic; /* pattern analysis + device-resident A_k values */
+typedef struct scilmm_factor scilmm_factor;     /* numeric factor L of V[P][:,P]                  */
+
+/* Ordering / supernode options; the counterpart of the reference's constructor kwargs
+ * SparseCholesky(use_long=False, mode='supernodal', ordering_method='nesdis') (SparseCholesky.py:17-20).
+ * Negative / zero fields mean "library default". */
+typedef struct scilmm_options {
+  int32_t ordering;     /* 0 = approximate minimum degree, 1 = natural, 2 = perm_in */
+  int32_t relax_small;  /* relaxed amalgamation: always merge when merged width <= this */
+  int32_t relax_w1, relax_w2;
+  double relax_z1, relax_z2, relax_z3;
+  double amd_dense;
+  int32_t max_width;    /* split supernodes wider than this (0 = library default) */
+} scilmm_options;
+
+typedef struct scilmm_info {
+  int32_t n, K, nsuper, nlevels;
+  int64_t nnzL;         /* sum_j colcount_j : algorithmic nonzeros of L (BASELINE metric nnz(L)/s) */
+  int64_t nnzL_stored;  /* doubles of supernodal panel storage */
+  int64_t nnz_pattern;  /* entries of tril(union pattern of the A_k) */
+  double flops;         /* sum_j colcount_j^2 (CHOLMOD "fl" convention) */
+  int64_t n_rows_total; /* sum_s m_s */
+  int64_t n_updates;    /* number of (target, descendant) update pairs */
+} scilmm_info;
+
+/* --- symbolic phase: replaces cholmod_analyze inside sk_cholesky (SparseCholesky.py:23-26), but once per
+ * pattern instead of once per evaluation.  indptr[k]/indices[k] is the CSR pattern of mats[k]; only
+ * entries with column <= row are read (the matrices are symmetric).  perm_in[new] = old or NULL. */
+int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
+                           const int32_t* perm_in, const scilmm_options* opts, int32_t ngpus,
+                           scilmm_symbolic** out);
+int scilmm_symbolic_info(const scilmm_symbolic* sym, scilmm_info* info);
+/* Copy a named int32/int64 array of the analysis ("perm" replaces factor.P(), SparseCholesky.py:93).
+ * Call with out == NULL to get the element count. */
+int scilmm_symbolic_get(const scilmm_symbolic* sym, const char* what, void* out, int64_t* count);
+const char* scilmm_symbolic_error(const scilmm_symbolic* sym);
+void scilmm_symbolic_free(scilmm_symbolic* sym);
+
+/* --- values: one upload per A_k replaces the per-evaluation CSR arithmetic of matrices_weighted_sum
+ * (SparseCholesky.py:55-59).  data_k is the CSR data array matching indptr[k]/indices[k]. */
+int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k);
+
+/* --- numeric phase: V = sum_k sigma2[k] A_k assembled on the device, then L L^T = V[P][:,P].
+ * Replaces matrices_weighted_sum + cholesky_func(V) (SparseCholesky.py:88,92).  A factor handle can be
+ * re-used: scilmm_refactorize overwrites its values for new sigma2. On SCILMM_ERR_NOT_PD,
+ * *bad_col receives the failing (permuted) column. */
+int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor** out, int32_t* bad_col);
+int scilmm_refactorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col);
+void scilmm_factor_free(scilmm_factor* fac);
+
+/* factor.logdet()  (SparseCholesky.py:40) */
+int scilmm_logdet(scilmm_factor* fac, double* out);
+/* factor(b): X = V^{-1} B, B and X row-major n x r  (SparseCholesky.py:30,32,52,100,149,153) */
+int scilmm_solve(scilmm_factor* fac, const double* B, int32_t r, double* X);
+/* (factor.L() @ R)[argsort(P)] : Z = P^T L R  (simulate_vector, SparseCholesky.py:50-51) */
+int scilmm_lmul(scilmm_factor* fac, const double* R, int32_t r, double* Z);
+/* factor.L() as CSC of the permuted factor (SparseCholesky.py:50); call with vals == NULL to get nnz. */
+int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double* vals, int64_t* nnz);
+/* out[j] = sum_i (A_k U)_ij U_ij  (compute_gradients, SparseCholesky.py:65-66,70); U row-major n x r */
+int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r, double* out);
+/* Y = A_k X, row-major n x r (SparseCholesky.py:66,70,160,163) */
+int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y);
+
+/* --- device-pointer variants used by bench.py and by callers that keep data resident in HBM */
+int scilmm_solve_dev(scilmm_factor* fac, const double* dB, int32_t r, double* dX);
+int scilmm_lmul_dev(scilmm_factor* fac, const double* dR, int32_t r, double* dZ);
+int scilmm_quadforms_dev(scilmm_symbolic* sym, int32_t k, const double* dU, int32_t r, double* d_out);
+int scilmm_sync(scilmm_symbolic* sym);
+
+/* --- measurement hooks (bench.py): HIP-event time of the last factorize / solve on the handle's
+ * stream, in milliseconds, split by phase. */
+typedef struct scilmm_timing {
+  double assemble_ms, factor_ms, solve_fwd_ms, solve_bwd_ms, lmul_ms, quad_ms;
+  int64_t n_launches;
+} scilmm_timing;
+int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
+
+const char* scilmm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCILMM_HIP_H */

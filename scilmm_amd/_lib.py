@@ -1,0 +1,133 @@
+"""ctypes binding of libscilmm_hip.so (include/scilmm_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a device call fails, an
+exception is raised.  (The CPU oracle lives under oracle/ and is only used by tests and bench.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SCILMM_HIP_LIB", os.path.join(_HERE, "csrc", "libscilmm_hip.so"))
+
+OK, ERR_ARG, ERR_NOT_PD, ERR_DEVICE, ERR_STATE = 0, -1, -2, -3, -4
+
+
+class ScilmmError(RuntimeError):
+    pass
+
+
+class NotPositiveDefiniteError(ScilmmError):
+    """Counterpart of sksparse.cholmod.CholmodNotPositiveDefiniteError at the reference boundary."""
+
+    def __init__(self, column):
+        super().__init__("matrix is not positive definite (failing permuted column %d)" % column)
+        self.column = column
+
+
+class Options(C.Structure):
+    _fields_ = [("ordering", C.c_int32), ("relax_small", C.c_int32), ("relax_w1", C.c_int32),
+                ("relax_w2", C.c_int32), ("relax_z1", C.c_double), ("relax_z2", C.c_double),
+                ("relax_z3", C.c_double), ("amd_dense", C.c_double), ("max_width", C.c_int32)]
+
+    @classmethod
+    def default(cls, ordering=0, **kw):
+        o = cls(ordering, -1, -1, -1, -1.0, -1.0, -1.0, 0.0, 0)
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+
+class Info(C.Structure):
+    _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("nsuper", C.c_int32), ("nlevels", C.c_int32),
+                ("nnzL", C.c_int64), ("nnzL_stored", C.c_int64), ("nnz_pattern", C.c_int64),
+                ("flops", C.c_double), ("n_rows_total", C.c_int64), ("n_updates", C.c_int64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("assemble_ms", C.c_double), ("factor_ms", C.c_double), ("solve_fwd_ms", C.c_double),
+                ("solve_bwd_ms", C.c_double), ("lmul_ms", C.c_double), ("quad_ms", C.c_double),
+                ("n_launches", C.c_int64)]
+
+
+# every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "scilmm_symbolic_create", "scilmm_symbolic_info", "scilmm_symbolic_get", "scilmm_symbolic_error",
+    "scilmm_symbolic_free", "scilmm_values_upload", "scilmm_factorize", "scilmm_refactorize",
+    "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
+    "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
+    "scilmm_sync", "scilmm_last_timing", "scilmm_version",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once). Raises ScilmmError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScilmmError("libscilmm_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (or make -C scilmm_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    P = C.POINTER
+    L.scilmm_symbolic_create.argtypes = [i32, i32, P(vp), P(vp), vp, P(Options), i32, P(vp)]
+    L.scilmm_symbolic_info.argtypes = [vp, P(Info)]
+    L.scilmm_symbolic_get.argtypes = [vp, C.c_char_p, vp, P(i64)]
+    L.scilmm_symbolic_error.argtypes = [vp]
+    L.scilmm_symbolic_error.restype = C.c_char_p
+    L.scilmm_symbolic_free.argtypes = [vp]
+    L.scilmm_symbolic_free.restype = None
+    L.scilmm_values_upload.argtypes = [vp, i32, vp]
+    L.scilmm_factorize.argtypes = [vp, vp, P(vp), P(i32)]
+    L.scilmm_refactorize.argtypes = [vp, vp, P(i32)]
+    L.scilmm_factor_free.argtypes = [vp]
+    L.scilmm_factor_free.restype = None
+    L.scilmm_logdet.argtypes = [vp, P(dbl)]
+    L.scilmm_solve.argtypes = [vp, vp, i32, vp]
+    L.scilmm_lmul.argtypes = [vp, vp, i32, vp]
+    L.scilmm_export_L.argtypes = [vp, vp, vp, vp, P(i64)]
+    L.scilmm_quadforms.argtypes = [vp, i32, vp, i32, vp]
+    L.scilmm_spmm.argtypes = [vp, i32, vp, i32, vp]
+    L.scilmm_solve_dev.argtypes = [vp, vp, i32, vp]
+    L.scilmm_lmul_dev.argtypes = [vp, vp, i32, vp]
+    L.scilmm_quadforms_dev.argtypes = [vp, i32, vp, i32, vp]
+    L.scilmm_sync.argtypes = [vp]
+    L.scilmm_last_timing.argtypes = [vp, P(Timing)]
+    L.scilmm_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(status, sym=None, bad_col=None):
+    if status == OK:
+        return
+    if status == ERR_NOT_PD:
+        raise NotPositiveDefiniteError(-1 if bad_col is None else int(bad_col))
+    msg = {ERR_ARG: "invalid argument", ERR_DEVICE: "HIP device error", ERR_STATE: "invalid call order"}.get(
+        status, "error %d" % status)
+    if sym:
+        detail = lib().scilmm_symbolic_error(sym)
+        if detail:
+            msg += ": " + detail.decode()
+    raise ScilmmError(msg)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_GET_DTYPES = {"sn_rowptr": np.int64, "sn_loff": np.int64, "asm_dst": np.int64, "diag_dst": np.int64,
+               "upd_ptr": np.int64, "tile_base": np.int64, "combo_ptr": np.int64, "level_tile_ptr": np.int64,
+               "level_pair_ptr": np.int64, "child_ptr": np.int64}
+
+
+def symbolic_get(sym, name):
+    n = C.c_int64(0)
+    check(lib().scilmm_symbolic_get(sym, name.encode(), None, C.byref(n)), sym)
+    out = np.empty(n.value, dtype=_GET_DTYPES.get(name, np.int32))
+    check(lib().scilmm_symbolic_get(sym, name.encode(), ptr(out), C.byref(n)), sym)
+    return out

@@ -1,0 +1,114 @@
+// C-ABI entry points for the host-side symbolic phase (no GPU needed). Declared in include/scilmm_hip.h.
+#include <cstring>
+#include <string>
+
+#include "../../include/scilmm_hip.h"
+#include "symbolic.h"
+
+using scilmm::Symbolic;
+
+struct scilmm_symbolic {
+  Symbolic* S = nullptr;
+  std::string err;
+  void* device = nullptr;  // owned by the numeric layer (capi_numeric.hip)
+  void (*device_free)(void*) = nullptr;
+};
+
+extern "C" {
+
+int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
+                           const int32_t* perm_in, const scilmm_options* opts, int32_t ngpus, scilmm_symbolic** out) {
+  (void)ngpus;
+  if (!out || n < 0 || K <= 0 || !indptr || !indices) return SCILMM_ERR_ARG;
+  scilmm::SymbolicOptions o;
+  if (opts) {
+    o.ordering = opts->ordering;
+    if (opts->relax_small >= 0) o.relax_small = opts->relax_small;
+    if (opts->relax_w1 >= 0) o.relax_w1 = opts->relax_w1;
+    if (opts->relax_w2 >= 0) o.relax_w2 = opts->relax_w2;
+    if (opts->relax_z1 >= 0) o.relax_z1 = opts->relax_z1;
+    if (opts->relax_z2 >= 0) o.relax_z2 = opts->relax_z2;
+    if (opts->relax_z3 >= 0) o.relax_z3 = opts->relax_z3;
+    if (opts->amd_dense != 0) o.amd_dense = opts->amd_dense;
+    if (opts->max_width != 0) o.max_width = opts->max_width < 0 ? 0 : opts->max_width;
+  }
+  if (perm_in && !opts) o.ordering = 2;
+  scilmm_symbolic* h = new scilmm_symbolic();
+  h->S = scilmm::symbolic_analyze(n, K, indptr, indices, perm_in, o);
+  *out = h;
+  if (!h->S->error.empty()) {
+    h->err = h->S->error;
+    return SCILMM_ERR_ARG;
+  }
+  return SCILMM_OK;
+}
+
+int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
+  if (!h || !h->S || !info) return SCILMM_ERR_ARG;
+  const Symbolic& S = *h->S;
+  info->n = S.n;
+  info->K = S.K;
+  info->nsuper = S.nsuper;
+  info->nlevels = S.nlevels;
+  info->nnzL = S.nnzL;
+  info->nnzL_stored = S.nnzL_stored;
+  info->nnz_pattern = S.nnz_pattern;
+  info->flops = S.flops;
+  info->n_rows_total = (int64_t)S.sn_rows.size();
+  info->n_updates = (int64_t)S.upd_src.size();
+  return SCILMM_OK;
+}
+
+#define GET(name, vec)                                                     \
+  if (!std::strcmp(what, name)) {                                          \
+    if (out) std::memcpy(out, S.vec.data(), S.vec.size() * sizeof(S.vec[0])); \
+    *count = (int64_t)S.vec.size();                                        \
+    return SCILMM_OK;                                                      \
+  }
+
+int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, int64_t* count) {
+  if (!h || !h->S || !what || !count) return SCILMM_ERR_ARG;
+  const Symbolic& S = *h->S;
+  GET("perm", perm)
+  GET("iperm", iperm)
+  GET("parent", parent)
+  GET("colcount", colcount)
+  GET("sn_start", sn_start)
+  GET("sn_parent", sn_parent)
+  GET("sn_rowptr", sn_rowptr)
+  GET("sn_rows", sn_rows)
+  GET("sn_loff", sn_loff)
+  GET("sn_level", sn_level)
+  GET("level_ptr", level_ptr)
+  GET("level_fronts", level_fronts)
+  GET("asm_dst", asm_dst)
+  GET("diag_dst", diag_dst)
+  GET("upd_ptr", upd_ptr)
+  GET("upd_src", upd_src)
+  GET("upd_p0", upd_p0)
+  GET("upd_p1", upd_p1)
+  GET("tile_base", tile_base)
+  GET("tile_front", tile_front)
+  GET("combo_ptr", combo_ptr)
+  GET("combo_pair", combo_pair)
+  GET("combo_ta", combo_ta)
+  GET("combo_tb", combo_tb)
+  GET("level_tile_ptr", level_tile_ptr)
+  GET("level_tiles", level_tiles)
+  GET("level_pair_ptr", level_pair_ptr)
+  GET("level_pairs", level_pairs)
+  GET("child_ptr", child_ptr)
+  GET("child_idx", child_idx)
+  return SCILMM_ERR_ARG;
+}
+
+const char* scilmm_symbolic_error(const scilmm_symbolic* h) { return h ? h->err.c_str() : "null handle"; }
+
+void scilmm_symbolic_free(scilmm_symbolic* h) {
+  if (!h) return;
+  if (h->device && h->device_free) h->device_free(h->device);
+  delete h->S;
+  delete h;
+}
+
+}  // extern "C"

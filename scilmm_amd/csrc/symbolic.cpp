@@ -1,0 +1,598 @@
+// Host-side symbolic analysis: union pattern, fill-reducing ordering, elimination tree, postorder,
+// column counts, (relaxed) supernodes, supernode row structures, left-looking update schedule,
+// value-assembly maps.  See symbolic.h.  Replaces cholmod_analyze as reached from the reference at
+// scilmm/SparseCholesky.py:22-26 / scilmm/Estimation/LMM.py:20-24, but runs once per pattern.
+//
+// All algorithms are written from their published descriptions (Liu 1990 elimination tree with
+// path compression; Gilbert, Ng & Peyton 1994 skeleton column counts; Ashcraft & Grimes 1989 relaxed
+// supernode amalgamation); no third-party source was available in this container.
+#include "symbolic.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cstring>
+#include <numeric>
+
+namespace scilmm {
+
+namespace {
+
+// CSC-lower (strict or with diagonal) <-> CSR-lower transpose of a pattern.
+void transpose_pattern(int32_t n, const std::vector<int64_t>& ptr, const std::vector<int32_t>& idx,
+                       std::vector<int64_t>& tptr, std::vector<int32_t>& tidx) {
+  tptr.assign(n + 1, 0);
+  for (int64_t e = 0; e < (int64_t)idx.size(); ++e) tptr[idx[e] + 1]++;
+  for (int32_t i = 0; i < n; ++i) tptr[i + 1] += tptr[i];
+  tidx.resize(idx.size());
+  std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+  for (int32_t j = 0; j < n; ++j)
+    for (int64_t e = ptr[j]; e < ptr[j + 1]; ++e) tidx[fill[idx[e]]++] = j;
+}
+
+// Liu's algorithm. rptr/ridx: for each row i the columns k < i with A_ik != 0.
+void etree(int32_t n, const std::vector<int64_t>& rptr, const std::vector<int32_t>& ridx, std::vector<int32_t>& parent) {
+  parent.assign(n, -1);
+  std::vector<int32_t> anc(n, -1);
+  for (int32_t i = 0; i < n; ++i) {
+    for (int64_t e = rptr[i]; e < rptr[i + 1]; ++e) {
+      int32_t k = ridx[e];
+      while (k != -1 && k < i) {
+        int32_t nx = anc[k];
+        anc[k] = i;
+        if (nx == -1) parent[k] = i;
+        k = nx;
+      }
+    }
+  }
+}
+
+// Postorder with children visited in increasing label order. post[k] = node visited k-th.
+void postorder(int32_t n, const std::vector<int32_t>& parent, std::vector<int32_t>& post) {
+  std::vector<int32_t> head(n, -1), next(n, -1);
+  for (int32_t j = n - 1; j >= 0; --j) {
+    if (parent[j] == -1) continue;
+    next[j] = head[parent[j]];
+    head[parent[j]] = j;
+  }
+  post.resize(n);
+  int32_t k = 0;
+  std::vector<int32_t> stack;
+  for (int32_t r = 0; r < n; ++r) {
+    if (parent[r] != -1) continue;
+    stack.push_back(r);
+    while (!stack.empty()) {
+      int32_t p = stack.back();
+      int32_t c = head[p];
+      if (c == -1) {
+        post[k++] = p;
+        stack.pop_back();
+      } else {
+        head[p] = next[c];
+        stack.push_back(c);
+      }
+    }
+  }
+}
+
+int32_t find_root(std::vector<int32_t>& anc, int32_t x) {
+  int32_t r = x;
+  while (anc[r] != r) r = anc[r];
+  while (anc[x] != r) {
+    int32_t nx = anc[x];
+    anc[x] = r;
+    x = nx;
+  }
+  return r;
+}
+
+// Skeleton column counts; labels are already postordered (post = identity).
+// cptr/cidx: for each column j the rows i > j with A_ij != 0.
+void column_counts(int32_t n, const std::vector<int32_t>& parent, const std::vector<int64_t>& cptr,
+                   const std::vector<int32_t>& cidx, std::vector<int32_t>& cc) {
+  std::vector<int32_t> first(n), size(n, 1);
+  for (int32_t j = 0; j < n; ++j)
+    if (parent[j] != -1) size[parent[j]] += size[j];
+  for (int32_t j = 0; j < n; ++j) first[j] = j - size[j] + 1;
+  std::vector<int64_t> delta(n);
+  for (int32_t j = 0; j < n; ++j) delta[j] = (size[j] == 1) ? 1 : 0;
+  std::vector<int32_t> maxfirst(n, -1), prevleaf(n, -1), anc(n);
+  std::iota(anc.begin(), anc.end(), 0);
+  for (int32_t j = 0; j < n; ++j) {
+    if (parent[j] != -1) delta[parent[j]]--;
+    for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+      int32_t i = cidx[e];
+      if (i <= j) continue;
+      if (first[j] <= maxfirst[i]) continue;  // j is not a leaf of row subtree i
+      maxfirst[i] = first[j];
+      int32_t jprev = prevleaf[i];
+      prevleaf[i] = j;
+      delta[j]++;
+      if (jprev != -1) {
+        int32_t q = find_root(anc, jprev);
+        delta[q]--;
+      }
+    }
+    if (parent[j] != -1) anc[j] = parent[j];
+  }
+  cc.resize(n);
+  for (int32_t j = 0; j < n; ++j) {
+    cc[j] = (int32_t)delta[j];
+    if (parent[j] != -1) delta[parent[j]] += delta[j];
+  }
+}
+
+}  // namespace
+
+Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
+                           const int32_t* perm_in, const SymbolicOptions& opts) {
+  Symbolic* S = new Symbolic();
+  S->n = n;
+  S->K = K;
+  // ---------------------------------------------------------------- 1. union lower pattern (original labels, by row)
+  S->is_diag.assign(K, 1);
+  std::vector<int64_t> uptr(n + 1, 0);
+  std::vector<int32_t> uidx;
+  {
+    std::vector<int64_t> cnt(n, 0);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < n; ++i) {
+      std::vector<int32_t> tmp;
+      tmp.push_back(i);
+      for (int32_t k = 0; k < K; ++k)
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+          int32_t j = indices[k][e];
+          if (j < 0 || j >= n) continue;
+          if (j <= i) tmp.push_back(j);
+        }
+      std::sort(tmp.begin(), tmp.end());
+      cnt[i] = std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+    }
+    for (int32_t i = 0; i < n; ++i) uptr[i + 1] = uptr[i] + cnt[i];
+    uidx.resize(uptr[n]);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < n; ++i) {
+      std::vector<int32_t> tmp;
+      tmp.push_back(i);
+      for (int32_t k = 0; k < K; ++k)
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+          int32_t j = indices[k][e];
+          if (j < 0 || j >= n) continue;
+          if (j <= i) tmp.push_back(j);
+        }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      std::copy(tmp.begin(), tmp.end(), uidx.begin() + uptr[i]);
+    }
+    for (int32_t k = 0; k < K; ++k) {
+      bool diag = true;
+      for (int32_t i = 0; i < n && diag; ++i)
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
+          if (indices[k][e] != i) { diag = false; break; }
+      S->is_diag[k] = diag ? 1 : 0;
+    }
+  }
+  S->nnz_pattern = uptr[n];
+
+  // ---------------------------------------------------------------- 2. ordering
+  std::vector<int32_t> perm(n);
+  if (opts.ordering == 2) {
+    if (!perm_in) { S->error = "user ordering requested but no permutation given"; return S; }
+    std::vector<uint8_t> seen(n, 0);
+    for (int32_t i = 0; i < n; ++i) {
+      int32_t p = perm_in[i];
+      if (p < 0 || p >= n || seen[p]) { S->error = "invalid user permutation"; return S; }
+      seen[p] = 1;
+      perm[i] = p;
+    }
+  } else if (opts.ordering == 1) {
+    std::iota(perm.begin(), perm.end(), 0);
+  } else {
+    // symmetric adjacency without the diagonal
+    std::vector<int64_t> gptr(n + 1, 0);
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
+        int32_t j = uidx[e];
+        if (j == i) continue;
+        gptr[i + 1]++;
+        gptr[j + 1]++;
+      }
+    for (int32_t i = 0; i < n; ++i) gptr[i + 1] += gptr[i];
+    std::vector<int32_t> gidx(gptr[n]);
+    std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
+        int32_t j = uidx[e];
+        if (j == i) continue;
+        gidx[fill[i]++] = j;
+        gidx[fill[j]++] = i;
+      }
+    amd_order(n, gptr.data(), gidx.data(), perm.data(), opts.amd_dense);
+  }
+  std::vector<int32_t> iperm(n);
+  for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
+
+  // ---------------------------------------------------------------- 3. permuted strict-lower pattern by column
+  auto build_csc = [&](const std::vector<int32_t>& ip, std::vector<int64_t>& cptr, std::vector<int32_t>& cidx) {
+    cptr.assign(n + 1, 0);
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
+        int32_t j = uidx[e];
+        if (j == i) continue;
+        int32_t a = ip[i], b = ip[j];
+        cptr[std::min(a, b) + 1]++;
+      }
+    for (int32_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
+    cidx.resize(cptr[n]);
+    std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
+        int32_t j = uidx[e];
+        if (j == i) continue;
+        int32_t a = ip[i], b = ip[j];
+        cidx[fill[std::min(a, b)]++] = std::max(a, b);
+      }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t j = 0; j < n; ++j) std::sort(cidx.begin() + cptr[j], cidx.begin() + cptr[j + 1]);
+  };
+  std::vector<int64_t> cptr, rptr;
+  std::vector<int32_t> cidx, ridx;
+  build_csc(iperm, cptr, cidx);
+  transpose_pattern(n, cptr, cidx, rptr, ridx);
+
+  // ---------------------------------------------------------------- 4. etree + postorder, relabel
+  std::vector<int32_t> parent;
+  etree(n, rptr, ridx, parent);
+  std::vector<int32_t> post;
+  postorder(n, parent, post);
+  {
+    std::vector<int32_t> perm2(n), pinv(n);
+    for (int32_t k = 0; k < n; ++k) {
+      perm2[k] = perm[post[k]];
+      pinv[post[k]] = k;
+    }
+    std::vector<int32_t> par2(n);
+    for (int32_t j = 0; j < n; ++j) par2[pinv[j]] = parent[j] == -1 ? -1 : pinv[parent[j]];
+    parent.swap(par2);
+    perm.swap(perm2);
+    for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
+    build_csc(iperm, cptr, cidx);
+    transpose_pattern(n, cptr, cidx, rptr, ridx);
+  }
+  S->perm = perm;
+  S->iperm = iperm;
+  S->parent = parent;
+
+  // ---------------------------------------------------------------- 5. column counts
+  std::vector<int32_t> cc;
+  column_counts(n, parent, cptr, cidx, cc);
+  S->colcount = cc;
+  S->nnzL = 0;
+  S->flops = 0;
+  for (int32_t j = 0; j < n; ++j) {
+    S->nnzL += cc[j];
+    S->flops += (double)cc[j] * (double)cc[j];
+  }
+
+  // ---------------------------------------------------------------- 6. supernodes (fundamental, then relaxed)
+  struct SN { int32_t start, end, m; int64_t zeros; };
+  std::vector<SN> out;
+  {
+    int32_t j = 0;
+    std::vector<int32_t> nchild(n, 0);
+    for (int32_t c = 0; c < n; ++c)
+      if (parent[c] != -1) nchild[parent[c]]++;
+    while (j < n) {
+      int32_t s = j;
+      while (j + 1 < n && parent[j] == j + 1 && cc[j + 1] == cc[j] - 1 && nchild[j + 1] == 1) ++j;
+      ++j;
+      SN p{s, j, cc[s], 0};
+      // relaxed amalgamation with the immediately preceding supernode while it is a child
+      while (!out.empty()) {
+        SN& c = out.back();
+        int32_t pc = parent[c.end - 1];
+        if (pc < p.start || pc >= p.end) break;
+        int64_t wc = c.end - c.start, wp = p.end - p.start;
+        int64_t mnew = wc + p.m;
+        int64_t wnew = wc + wp;
+        int64_t z = c.zeros + p.zeros + wc * (wc + p.m - c.m);
+        double tot = (double)wnew * (double)mnew - (double)wnew * (double)(wnew - 1) / 2.0;
+        double frac = (double)z / tot;
+        bool merge = (wnew <= opts.relax_small) || (wnew <= opts.relax_w1 && frac < opts.relax_z1) ||
+                     (wnew <= opts.relax_w2 && frac < opts.relax_z2) || (frac < opts.relax_z3);
+        if (opts.max_width > 0 && wnew > opts.max_width) merge = false;
+        if (!merge) break;
+        p.start = c.start;
+        p.m = (int32_t)mnew;
+        p.zeros = z;
+        out.pop_back();
+      }
+      out.push_back(p);
+    }
+  }
+  // optional splitting of very wide supernodes (keeps kernels' LDS tiles bounded)
+  if (opts.max_width > 0) {
+    std::vector<SN> sp;
+    for (auto& s : out) {
+      int32_t w = s.end - s.start;
+      if (w <= opts.max_width) { sp.push_back(s); continue; }
+      int32_t nparts = (w + opts.max_width - 1) / opts.max_width;
+      int32_t base = w / nparts, rem = w % nparts, st = s.start;
+      for (int32_t p = 0; p < nparts; ++p) {
+        int32_t ww = base + (p < rem ? 1 : 0);
+        sp.push_back(SN{st, st + ww, s.m - (st - s.start), 0});
+        st += ww;
+      }
+    }
+    out.swap(sp);
+  }
+  int32_t ns = (int32_t)out.size();
+  S->nsuper = ns;
+  S->sn_start.resize(ns + 1);
+  for (int32_t s = 0; s < ns; ++s) S->sn_start[s] = out[s].start;
+  S->sn_start[ns] = n;
+  std::vector<int32_t> snode_of(n);
+  for (int32_t s = 0; s < ns; ++s)
+    for (int32_t j = out[s].start; j < out[s].end; ++j) snode_of[j] = s;
+
+  // ---------------------------------------------------------------- 7. row structure of every supernode
+  S->sn_rowptr.assign(ns + 1, 0);
+  S->sn_parent.assign(ns, -1);
+  {
+    // children lists are discovered on the fly: a child always precedes its parent
+    std::vector<int32_t> chead(ns, -1), cnext(ns, -1);
+    std::vector<int32_t> mark(n, -1);
+    std::vector<int32_t> tmp;
+    S->sn_rows.reserve((size_t)(S->nnzL / 4 + n));
+    for (int32_t s = 0; s < ns; ++s) {
+      int32_t c0 = out[s].start, c1 = out[s].end;
+      tmp.clear();
+      for (int32_t j = c0; j < c1; ++j) {
+        mark[j] = s;
+        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+          int32_t i = cidx[e];
+          if (i >= c1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+        }
+      }
+      for (int32_t c = chead[s]; c != -1; c = cnext[c]) {
+        int64_t b = S->sn_rowptr[c], e2 = S->sn_rowptr[c + 1];
+        int32_t wc = out[c].end - out[c].start;
+        for (int64_t e = b + wc; e < e2; ++e) {
+          int32_t i = S->sn_rows[e];
+          if (i >= c1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
+        }
+      }
+      std::sort(tmp.begin(), tmp.end());
+      for (int32_t j = c0; j < c1; ++j) S->sn_rows.push_back(j);
+      S->sn_rows.insert(S->sn_rows.end(), tmp.begin(), tmp.end());
+      S->sn_rowptr[s + 1] = (int64_t)S->sn_rows.size();
+      if (!tmp.empty()) {
+        int32_t p = snode_of[tmp[0]];
+        S->sn_parent[s] = p;
+        cnext[s] = chead[p];
+        chead[p] = s;
+      }
+    }
+  }
+  // ---------------------------------------------------------------- 8. panel offsets, levels
+  S->sn_loff.assign(ns + 1, 0);
+  for (int32_t s = 0; s < ns; ++s) {
+    int64_t m = S->sn_rowptr[s + 1] - S->sn_rowptr[s];
+    int64_t w = out[s].end - out[s].start;
+    int64_t sz = m * w;
+    sz = (sz + 1) & ~(int64_t)1;  // keep every panel 16-byte aligned
+    S->sn_loff[s + 1] = S->sn_loff[s] + sz;
+  }
+  S->nnzL_stored = S->sn_loff[ns];
+  S->sn_level.assign(ns, 0);
+  for (int32_t s = 0; s < ns; ++s) {
+    int32_t p = S->sn_parent[s];
+    if (p != -1) S->sn_level[p] = std::max(S->sn_level[p], S->sn_level[s] + 1);
+  }
+  S->nlevels = 0;
+  for (int32_t s = 0; s < ns; ++s) S->nlevels = std::max(S->nlevels, S->sn_level[s] + 1);
+
+  // children lists (increasing order)
+  S->child_ptr.assign(ns + 1, 0);
+  for (int32_t s = 0; s < ns; ++s)
+    if (S->sn_parent[s] != -1) S->child_ptr[S->sn_parent[s] + 1]++;
+  for (int32_t s = 0; s < ns; ++s) S->child_ptr[s + 1] += S->child_ptr[s];
+  S->child_idx.resize(S->child_ptr[ns]);
+  {
+    std::vector<int64_t> fill(S->child_ptr.begin(), S->child_ptr.end() - 1);
+    for (int32_t s = 0; s < ns; ++s)
+      if (S->sn_parent[s] != -1) S->child_idx[fill[S->sn_parent[s]]++] = s;
+  }
+
+  // ---------------------------------------------------------------- 9. value-assembly maps
+  // pattern slots are numbered in permuted CSC order with the diagonal first in each column.
+  {
+    std::vector<int64_t> slot_ptr(n + 1, 0);
+    for (int32_t j = 0; j < n; ++j) slot_ptr[j + 1] = slot_ptr[j] + 1 + (cptr[j + 1] - cptr[j]);
+    S->asm_dst.resize(slot_ptr[n]);
+    S->diag_dst.resize(n);
+    std::vector<int32_t> pos(n, -1);
+    for (int32_t s = 0; s < ns; ++s) {
+      int64_t rb = S->sn_rowptr[s], re = S->sn_rowptr[s + 1];
+      int64_t m = re - rb;
+      for (int64_t t = rb; t < re; ++t) pos[S->sn_rows[t]] = (int32_t)(t - rb);
+      for (int32_t j = out[s].start; j < out[s].end; ++j) {
+        int64_t colbase = S->sn_loff[s] + (int64_t)(j - out[s].start) * m;
+        int64_t sl = slot_ptr[j];
+        S->asm_dst[sl] = colbase + (j - out[s].start);
+        S->diag_dst[j] = S->asm_dst[sl];
+        ++sl;
+        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) S->asm_dst[sl++] = colbase + pos[cidx[e]];
+      }
+    }
+    // per input matrix: where does each stored lower entry go
+    S->val_slot.resize(K);
+    S->val_src.resize(K);
+    for (int32_t k = 0; k < K; ++k) {
+      if (S->is_diag[k]) continue;
+      int64_t cntk = 0;
+      for (int32_t i = 0; i < n; ++i)
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
+          if (indices[k][e] <= i && indices[k][e] >= 0) cntk++;
+      S->val_slot[k].resize(cntk);
+      S->val_src[k].resize(cntk);
+      std::vector<int64_t> rowoff(n + 1, 0);
+      for (int32_t i = 0; i < n; ++i) {
+        int64_t c = 0;
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
+          if (indices[k][e] <= i && indices[k][e] >= 0) c++;
+        rowoff[i + 1] = rowoff[i] + c;
+      }
+#pragma omp parallel for schedule(dynamic, 1024)
+      for (int32_t i = 0; i < n; ++i) {
+        int64_t o = rowoff[i];
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+          int32_t j = indices[k][e];
+          if (j > i || j < 0) continue;
+          int32_t a = iperm[i], b = iperm[j];
+          int32_t col = std::min(a, b), row = std::max(a, b);
+          int64_t sl;
+          if (row == col) {
+            sl = slot_ptr[col];
+          } else {
+            const int32_t* lo = cidx.data() + cptr[col];
+            const int32_t* hi = cidx.data() + cptr[col + 1];
+            const int32_t* it = std::lower_bound(lo, hi, row);
+            sl = slot_ptr[col] + 1 + (it - lo);
+          }
+          S->val_slot[k][o] = sl;
+          S->val_src[k][o] = e;
+          ++o;
+        }
+      }
+    }
+    S->nnz_pattern = slot_ptr[n];
+  }
+  // ---------------------------------------------------------------- 10. left-looking update schedule
+  {
+    S->upd_ptr.assign(ns + 1, 0);
+    for (int32_t d = 0; d < ns; ++d) {
+      int64_t rb = S->sn_rowptr[d], re = S->sn_rowptr[d + 1];
+      int32_t w = out[d].end - out[d].start;
+      int32_t prev = -1;
+      for (int64_t t = rb + w; t < re; ++t) {
+        int32_t s = snode_of[S->sn_rows[t]];
+        if (s != prev) { S->upd_ptr[s + 1]++; prev = s; }
+      }
+    }
+    for (int32_t s = 0; s < ns; ++s) S->upd_ptr[s + 1] += S->upd_ptr[s];
+    int64_t nu = S->upd_ptr[ns];
+    S->upd_src.resize(nu);
+    S->upd_p0.resize(nu);
+    S->upd_p1.resize(nu);
+    std::vector<int64_t> fill(S->upd_ptr.begin(), S->upd_ptr.end() - 1);
+    for (int32_t d = 0; d < ns; ++d) {  // increasing d => each target's list is in increasing descendant order
+      int64_t rb = S->sn_rowptr[d], re = S->sn_rowptr[d + 1];
+      int32_t w = out[d].end - out[d].start;
+      int64_t t = rb + w;
+      while (t < re) {
+        int32_t s = snode_of[S->sn_rows[t]];
+        int64_t t2 = t;
+        while (t2 < re && snode_of[S->sn_rows[t2]] == s) ++t2;
+        int64_t f = fill[s]++;
+        S->upd_src[f] = d;
+        S->upd_p0[f] = (int32_t)(t - rb);
+        S->upd_p1[f] = (int32_t)(t2 - rb);
+        t = t2;
+      }
+    }
+  }
+  // level lists, big fronts first inside a level
+  S->level_ptr.assign(S->nlevels + 1, 0);
+  for (int32_t s = 0; s < ns; ++s) S->level_ptr[S->sn_level[s] + 1]++;
+  for (int32_t l = 0; l < S->nlevels; ++l) S->level_ptr[l + 1] += S->level_ptr[l];
+  S->level_fronts.resize(ns);
+  {
+    std::vector<int32_t> fill(S->level_ptr.begin(), S->level_ptr.end() - 1);
+    for (int32_t s = 0; s < ns; ++s) S->level_fronts[fill[S->sn_level[s]]++] = s;
+  }
+  // ---------------------------------------------------------------- 11. target tiles and their combos
+  {
+    const int32_t TM = opts.tile_rows;
+    S->tile_rows = TM;
+    S->tile_base.assign(ns + 1, 0);
+    for (int32_t s = 0; s < ns; ++s) {
+      int64_t m = S->sn_rowptr[s + 1] - S->sn_rowptr[s];
+      S->tile_base[s + 1] = S->tile_base[s] + (m + TM - 1) / TM;
+    }
+    int64_t nt = S->tile_base[ns];
+    S->tile_front.resize(nt);
+    for (int32_t s = 0; s < ns; ++s)
+      for (int64_t g = S->tile_base[s]; g < S->tile_base[s + 1]; ++g) S->tile_front[g] = s;
+    // pass 1: count combos per tile, pass 2: fill. Rows of d beyond p0 are merged against rows of s.
+    std::vector<int64_t> cnt(nt + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<int64_t> fill;
+      if (pass == 1) {
+        for (int64_t g = 0; g < nt; ++g) cnt[g + 1] += cnt[g];
+        S->combo_ptr.assign(cnt.begin(), cnt.end());
+        S->combo_pair.resize(cnt[nt]);
+        S->combo_ta.resize(cnt[nt]);
+        S->combo_tb.resize(cnt[nt]);
+        fill.assign(cnt.begin(), cnt.end() - 1);
+      }
+#pragma omp parallel for schedule(dynamic, 64)
+      for (int32_t s = 0; s < ns; ++s) {
+        const int32_t* rs = S->sn_rows.data() + S->sn_rowptr[s];
+        int64_t ms = S->sn_rowptr[s + 1] - S->sn_rowptr[s];
+        for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) {
+          int32_t d = S->upd_src[e];
+          const int32_t* rd = S->sn_rows.data() + S->sn_rowptr[d];
+          int32_t md = (int32_t)(S->sn_rowptr[d + 1] - S->sn_rowptr[d]);
+          int32_t t = S->upd_p0[e];
+          int64_t pos = 0;
+          while (t < md) {
+            // position of rd[t] in rs (exists by construction): gallop from the previous position
+            const int32_t* it = std::lower_bound(rs + pos, rs + ms, rd[t]);
+            pos = it - rs;
+            int64_t tile = pos / TM;
+            int64_t tile_end_pos = std::min<int64_t>((tile + 1) * TM, ms);
+            int32_t lastlabel = rs[tile_end_pos - 1];
+            int32_t t2 = (int32_t)(std::upper_bound(rd + t, rd + md, lastlabel) - rd);
+            int64_t g = S->tile_base[s] + tile;
+            if (pass == 0) {
+              cnt[g + 1]++;   // each (s) handled by exactly one thread: no race on its own tiles
+            } else {
+              int64_t f = fill[g]++;
+              S->combo_pair[f] = (int32_t)e;
+              S->combo_ta[f] = t;
+              S->combo_tb[f] = t2;
+            }
+            t = t2;
+          }
+        }
+      }
+    }
+    // per-level tile lists, heaviest (most combos) first for load balance
+    S->level_tile_ptr.assign(S->nlevels + 1, 0);
+    for (int64_t g = 0; g < nt; ++g) S->level_tile_ptr[S->sn_level[S->tile_front[g]] + 1]++;
+    for (int32_t l = 0; l < S->nlevels; ++l) S->level_tile_ptr[l + 1] += S->level_tile_ptr[l];
+    S->level_tiles.resize(nt);
+    {
+      std::vector<int64_t> fill(S->level_tile_ptr.begin(), S->level_tile_ptr.end() - 1);
+      for (int64_t g = 0; g < nt; ++g) S->level_tiles[fill[S->sn_level[S->tile_front[g]]]++] = (int32_t)g;
+      for (int32_t l = 0; l < S->nlevels; ++l)
+        std::stable_sort(S->level_tiles.begin() + S->level_tile_ptr[l], S->level_tiles.begin() + S->level_tile_ptr[l + 1],
+                         [&](int32_t a, int32_t b) {
+                           return (S->combo_ptr[a + 1] - S->combo_ptr[a]) > (S->combo_ptr[b + 1] - S->combo_ptr[b]);
+                         });
+    }
+    // per-level update-pair lists (by target level)
+    S->level_pair_ptr.assign(S->nlevels + 1, 0);
+    for (int32_t s = 0; s < ns; ++s) S->level_pair_ptr[S->sn_level[s] + 1] += S->upd_ptr[s + 1] - S->upd_ptr[s];
+    for (int32_t l = 0; l < S->nlevels; ++l) S->level_pair_ptr[l + 1] += S->level_pair_ptr[l];
+    S->level_pairs.resize(S->upd_src.size());
+    {
+      std::vector<int64_t> fill(S->level_pair_ptr.begin(), S->level_pair_ptr.end() - 1);
+      for (int32_t s = 0; s < ns; ++s)
+        for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) S->level_pairs[fill[S->sn_level[s]]++] = (int32_t)e;
+    }
+  }
+  return S;
+}
+
+}  // namespace scilmm

@@ -1,0 +1,88 @@
+// Host-side symbolic analysis for the supernodal multifrontal Cholesky of V = sum_k s2_k A_k.
+// Built once per sparsity pattern (the reference redoes it on every evaluation:
+// scilmm/SparseCholesky.py:22-26,92).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace scilmm {
+
+void amd_order(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, int32_t* perm_out, double dense_factor);
+
+struct SymbolicOptions {
+  int32_t ordering = 0;        // 0 = AMD, 1 = natural, 2 = user permutation
+  int32_t relax_small = 4;     // always merge a child when the merged width is <= this
+  int32_t relax_w1 = 16;       // merged width <= relax_w1 -> allow zero fraction z1
+  int32_t relax_w2 = 48;       // merged width <= relax_w2 -> allow zero fraction z2
+  double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.05;
+  double amd_dense = 10.0;     // rows with degree > amd_dense*sqrt(n) are ordered last
+  int32_t max_width = 64;      // split supernodes wider than this (0 = unlimited)
+  int32_t tile_rows = 128;     // rows per target tile of the update kernel
+};
+
+// Everything the numeric phase needs.  "Front" s owns columns [sn_start[s], sn_start[s+1]) of the
+// permuted matrix, has m = rows.size() rows (the first w are its own columns), stores its
+// m x w column-major panel at L offset sn_loff[s] (leading dimension m).
+struct Symbolic {
+  int32_t n = 0;
+  int32_t K = 0;
+  std::vector<int32_t> perm;      // perm[new] = old   (factor is of V[perm][:,perm])
+  std::vector<int32_t> iperm;     // iperm[old] = new
+  std::vector<int32_t> parent;    // column etree (postordered labels)
+  std::vector<int32_t> colcount;  // nnz of each column of L (without relaxation zeros)
+  int32_t nsuper = 0;
+  std::vector<int32_t> sn_start;  // [nsuper+1]
+  std::vector<int32_t> sn_parent; // [nsuper]  -1 for roots
+  std::vector<int64_t> sn_rowptr; // [nsuper+1] into sn_rows
+  std::vector<int32_t> sn_rows;   // row lists (sorted; permuted labels)
+  std::vector<int64_t> sn_loff;   // [nsuper+1] offsets of the panels in L storage (doubles)
+  std::vector<int32_t> sn_level;  // [nsuper] height above the leaves
+  // children lists
+  std::vector<int64_t> child_ptr; // [nsuper+1]
+  std::vector<int32_t> child_idx; // children of each front in increasing order
+  // left-looking update schedule: target supernode s receives, for every e in
+  // [upd_ptr[s], upd_ptr[s+1]), the update  L_d[p0:m_d, :] * L_d[p0:p1, :]^T  from descendant
+  // d = upd_src[e], where rows p0..p1-1 of d are exactly the rows of d that fall in the columns of s.
+  std::vector<int64_t> upd_ptr;   // [nsuper+1]
+  std::vector<int32_t> upd_src;   // descendant supernode
+  std::vector<int32_t> upd_p0, upd_p1;
+  // row tiles of the target panels (tile_rows rows each) and, per tile, the list of descendant
+  // row ranges that contribute to it: combo c of tile g = pair combo_pair[c] restricted to rows
+  // [combo_ta[c], combo_tb[c]) of the descendant (all of which land inside the tile).
+  int32_t tile_rows = 128;
+  std::vector<int64_t> tile_base;   // [nsuper+1] first global tile id of each front
+  std::vector<int32_t> tile_front;  // [ntiles] owning front
+  std::vector<int64_t> combo_ptr;   // [ntiles+1]
+  std::vector<int32_t> combo_pair;  // index into upd_src/upd_p0/upd_p1
+  std::vector<int32_t> combo_ta, combo_tb;
+  std::vector<int64_t> level_tile_ptr; // [nlevels+1] tiles of level l are level_tiles[ptr[l]..ptr[l+1])
+  std::vector<int32_t> level_tiles;    // global tile ids sorted by level (heaviest first)
+  std::vector<int64_t> level_pair_ptr; // [nlevels+1] update pairs whose TARGET is in level l
+  std::vector<int32_t> level_pairs;
+  // level schedule: fronts sorted by (level, size class)
+  int32_t nlevels = 0;
+  std::vector<int32_t> level_ptr; // [nlevels+1] into level_fronts
+  std::vector<int32_t> level_fronts;
+  // assembly: union lower pattern in permuted CSC order; entry e goes to L[asm_dst[e]]
+  int64_t nnz_pattern = 0;        // entries of tril(union pattern)
+  std::vector<int64_t> asm_dst;   // [nnz_pattern]
+  std::vector<int64_t> diag_dst;  // [n] L offset of each diagonal entry (permuted order)
+  // per input matrix k: for each stored lower entry (CSR order, j<=i) the pattern slot it lands in
+  // (so values_upload can permute data_k into pattern order); empty for diagonal-only matrices
+  std::vector<std::vector<int64_t>> val_slot;   // [K][nnz_lower_k]
+  std::vector<std::vector<int64_t>> val_src;    // [K][nnz_lower_k] index into data_k
+  std::vector<uint8_t> is_diag;                 // [K] matrix k has a diagonal-only pattern
+  // statistics
+  int64_t nnzL = 0;        // true nonzeros of L (sum colcount)
+  int64_t nnzL_stored = 0; // doubles of panel storage (includes relaxation zeros and the upper part of diagonal blocks)
+  double flops = 0;        // sum colcount^2
+  std::string error;
+};
+
+// indptr[k]/indices[k]: CSR of matrix k (both triangles or lower only; only j<=i is read).
+// perm_in: optional user permutation (perm_in[new] = old), required when opts.ordering == 2.
+Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
+                           const int32_t* perm_in, const SymbolicOptions& opts);
+
+}  // namespace scilmm
