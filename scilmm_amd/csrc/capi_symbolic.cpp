@@ -3,16 +3,9 @@
 #include <string>
 
 #include "../../include/scilmm_hip.h"
-#include "symbolic.h"
+#include "handles.h"
 
 using scilmm::Symbolic;
-
-struct scilmm_symbolic {
-  Symbolic* S = nullptr;
-  std::string err;
-  void* device = nullptr;  // owned by the numeric layer (capi_numeric.hip)
-  void (*device_free)(void*) = nullptr;
-};
 
 extern "C" {
 
@@ -97,6 +90,9 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
   GET("level_tiles", level_tiles)
   GET("level_pair_ptr", level_pair_ptr)
   GET("level_pairs", level_pairs)
+  GET("pat_colptr", pat_colptr)
+  GET("pat_row", pat_row)
+  GET("inv_off", inv_off)
   GET("child_ptr", child_ptr)
   GET("child_idx", child_idx)
   return SCILMM_ERR_ARG;

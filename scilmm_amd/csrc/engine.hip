@@ -1,0 +1,624 @@
+// Host side of the numeric phase: device-resident symbolic arrays and A_k values, the level-scheduled
+// launch sequences (factorize / solve / L*R / quadratic forms) and the numeric C-ABI entry points of
+// include/scilmm_hip.h.  Everything runs on one HIP stream per symbolic handle; host entry points
+// synchronise only where they hand data back to the caller.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scilmm_hip.h"
+#include "kernels.hip.h"
+#include "handles.h"
+
+using namespace scilmm;
+
+namespace {
+
+struct Dev {
+  hipStream_t stream = nullptr;
+  DevSym v{};
+  std::vector<void*> allocs;
+  int32_t* d_level_tiles = nullptr;
+  int32_t* d_level_fronts = nullptr;
+  int32_t* d_level_pairs = nullptr;
+  int32_t* d_all_tiles = nullptr;  // identity list of tiles that carry rows (for L*R)
+  std::vector<double*> vals;       // per matrix: pattern-order values or diagonal values
+  std::vector<uint8_t> have_vals;
+  double* W = nullptr;             // n x RPMAX workspaces (permuted right-hand sides)
+  double* X = nullptr;
+  double* IO = nullptr;            // staging for host<->device dense transfers
+  size_t io_cap = 0;
+  double* partial = nullptr;
+  int64_t nwaves_quad = 0;
+  double* d_out = nullptr;         // RPMAX doubles
+  bool use_mfma = true;
+  hipEvent_t ev[8];
+  scilmm_timing timing{};
+  bool attrs_set = false;
+};
+
+#define HIPCHK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (call);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      sym->err = std::string(#call) + ": " + hipGetErrorString(_e);                                    \
+      return SCILMM_ERR_DEVICE;                                                                        \
+    }                                                                                                  \
+  } while (0)
+
+template <typename T>
+int upload(scilmm_symbolic* sym, Dev* D, const std::vector<T>& h, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc(&p, bytes));
+  D->allocs.push_back(p);
+  if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return SCILMM_OK;
+}
+
+void dev_free(void* p) {
+  Dev* D = (Dev*)p;
+  if (!D) return;
+  for (void* a : D->allocs) (void)hipFree(a);
+  for (double* v : D->vals)
+    if (v) (void)hipFree(v);
+  if (D->W) (void)hipFree(D->W);
+  if (D->X) (void)hipFree(D->X);
+  if (D->IO) (void)hipFree(D->IO);
+  if (D->partial) (void)hipFree(D->partial);
+  if (D->d_out) (void)hipFree(D->d_out);
+  for (auto& e : D->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (D->stream) (void)hipStreamDestroy(D->stream);
+  delete D;
+}
+
+int ensure_device(scilmm_symbolic* sym, Dev** out) {
+  if (sym->device) {
+    *out = (Dev*)sym->device;
+    return SCILMM_OK;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    sym->err = "no HIP device available (the numeric phase has no CPU fallback)";
+    return SCILMM_ERR_DEVICE;
+  }
+  Dev* D = new Dev();
+  sym->device = D;
+  sym->device_free = dev_free;
+  for (auto& e : D->ev) e = nullptr;
+  const Symbolic& S = *sym->S;
+  HIPCHK(hipStreamCreate(&D->stream));
+  for (auto& e : D->ev) HIPCHK(hipEventCreate(&e));
+  const char* nm = getenv("SCILMM_NO_MFMA");
+  D->use_mfma = !(nm && nm[0] == '1');
+  D->v.n = S.n;
+  D->v.nsuper = S.nsuper;
+  int st;
+#define UP(field, vec)                                          \
+  if ((st = upload(sym, D, S.vec, &D->v.field)) != SCILMM_OK) return st;
+  UP(sn_start, sn_start)
+  UP(sn_rowptr, sn_rowptr)
+  UP(sn_rows, sn_rows)
+  UP(sn_loff, sn_loff)
+  UP(inv_off, inv_off)
+  UP(upd_src, upd_src)
+  UP(upd_p0, upd_p0)
+  UP(upd_p1, upd_p1)
+  UP(tile_front, tile_front)
+  UP(tile_base, tile_base)
+  UP(combo_ptr, combo_ptr)
+  UP(combo_pair, combo_pair)
+  UP(combo_ta, combo_ta)
+  UP(combo_tb, combo_tb)
+  UP(asm_dst, asm_dst)
+  UP(diag_dst, diag_dst)
+  UP(pat_colptr, pat_colptr)
+  UP(pat_row, pat_row)
+  UP(perm, perm)
+#undef UP
+  const int32_t* tmp;
+  if ((st = upload(sym, D, S.level_tiles, &tmp)) != SCILMM_OK) return st;
+  D->d_level_tiles = (int32_t*)tmp;
+  if ((st = upload(sym, D, S.level_fronts, &tmp)) != SCILMM_OK) return st;
+  D->d_level_fronts = (int32_t*)tmp;
+  if ((st = upload(sym, D, S.level_pairs, &tmp)) != SCILMM_OK) return st;
+  D->d_level_pairs = (int32_t*)tmp;
+  D->vals.assign(S.K, nullptr);
+  D->have_vals.assign(S.K, 0);
+  HIPCHK(hipMalloc((void**)&D->d_out, sizeof(double) * RPMAX));
+  *out = D;
+  return SCILMM_OK;
+}
+
+int set_attrs(scilmm_symbolic* sym, Dev* D) {
+  if (D->attrs_set) return SCILMM_OK;
+  const int big = 150 * 1024;
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  D->attrs_set = true;
+  return SCILMM_OK;
+}
+
+int ensure_work(scilmm_symbolic* sym, Dev* D) {
+  const Symbolic& S = *sym->S;
+  size_t bytes = (size_t)std::max(S.n, 1) * RPMAX * sizeof(double);
+  if (!D->W) HIPCHK(hipMalloc((void**)&D->W, bytes));
+  if (!D->X) HIPCHK(hipMalloc((void**)&D->X, bytes));
+  return set_attrs(sym, D);
+}
+
+int ensure_io(scilmm_symbolic* sym, Dev* D, size_t doubles) {
+  if (D->io_cap >= doubles) return SCILMM_OK;
+  if (D->IO) (void)hipFree(D->IO);
+  D->IO = nullptr;
+  D->io_cap = 0;
+  HIPCHK(hipMalloc((void**)&D->IO, std::max<size_t>(doubles, 1) * sizeof(double)));
+  D->io_cap = doubles;
+  return SCILMM_OK;
+}
+
+inline int rp_of(int rc) { return (rc + 15) & ~15; }
+inline int ldy_of(int rp) { return (rp % 32 == 16) ? rp : rp + 16; }
+
+}  // namespace
+
+struct scilmm_factor {
+  scilmm_symbolic* sym = nullptr;
+  double* L = nullptr;
+  double* invD = nullptr;
+  double* logd = nullptr;
+  int32_t* status = nullptr;
+  bool valid = false;
+};
+
+namespace {
+
+int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
+  scilmm_symbolic* sym = fac->sym;
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  for (int k = 0; k < S.K; ++k)
+    if (!D->have_vals[k]) {
+      sym->err = "scilmm_values_upload has not been called for every matrix";
+      return SCILMM_ERR_STATE;
+    }
+  fac->valid = false;
+  hipStream_t st = D->stream;
+  int64_t launches = 0;
+  HIPCHK(hipEventRecord(D->ev[0], st));
+  HIPCHK(hipMemsetAsync(fac->L, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nnzL_stored, 1), st));
+  int32_t big = 0x7fffffff;
+  HIPCHK(hipMemcpyAsync(fac->status, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  ValPtrs gen{}, dia{};
+  for (int k = 0; k < S.K; ++k) {
+    ValPtrs& t = S.is_diag[k] ? dia : gen;
+    if (t.count >= 8) {
+      sym->err = "more than 8 matrices of one kind";
+      return SCILMM_ERR_ARG;
+    }
+    t.v[t.count] = D->vals[k];
+    t.s2[t.count] = sigma2[k];
+    t.count++;
+  }
+  if (S.nnz_pattern > 0) {
+    int blocks = (int)std::min<int64_t>((S.nnz_pattern + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, st, S.nnz_pattern, D->v.asm_dst, gen, fac->L);
+    launches++;
+  }
+  if (dia.count > 0 && S.n > 0) {
+    hipLaunchKernelGGL(k_add_diag, dim3((S.n + 255) / 256), dim3(256), 0, st, S.n, D->v.diag_dst, dia, fac->L);
+    launches++;
+  }
+  HIPCHK(hipEventRecord(D->ev[1], st));
+  for (int32_t l = 0; l < S.nlevels; ++l) {
+    const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
+    const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
+    if (l > 0 && t1 > t0) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_update<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L);
+      else
+        hipLaunchKernelGGL(k_update<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L);
+      launches++;
+    }
+    if (f1 > f0) {
+      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
+                         fac->invD, fac->logd, fac->status);
+      launches++;
+    }
+    if (t1 > t0) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
+                           fac->invD);
+      else
+        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
+                           fac->invD);
+      launches++;
+    }
+  }
+  HIPCHK(hipEventRecord(D->ev[2], st));
+  HIPCHK(hipGetLastError());
+  int32_t status = 0;
+  HIPCHK(hipMemcpyAsync(&status, fac->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  float a = 0, f = 0;
+  HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
+  HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));
+  D->timing.assemble_ms = a;
+  D->timing.factor_ms = f;
+  D->timing.n_launches = launches;
+  if (status != 0x7fffffff) {
+    if (bad_col) *bad_col = status;
+    return SCILMM_ERR_NOT_PD;
+  }
+  fac->valid = true;
+  return SCILMM_OK;
+}
+
+// dB/dX: device, row-major n x r, ORIGINAL row order.  mode 0: X = V^-1 B.  mode 1: X = P^T L B.
+int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mode) {
+  scilmm_symbolic* sym = fac->sym;
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  if (!fac->valid) {
+    sym->err = "factor is not valid";
+    return SCILMM_ERR_STATE;
+  }
+  int stc = ensure_work(sym, D);
+  if (stc != SCILMM_OK) return stc;
+  hipStream_t st = D->stream;
+  const int64_t ntiles_all = (int64_t)S.level_tiles.size();
+  const bool mf = D->use_mfma;
+  HIPCHK(hipEventRecord(D->ev[3], st));
+  bool mid_recorded = false;
+  for (int32_t cbeg = 0; cbeg < r; cbeg += RPMAX) {
+    const int rc = std::min<int>(RPMAX, r - cbeg);
+    const int rp = rp_of(rc), ldy = ldy_of(rp);
+    const int64_t tot = (int64_t)S.n * rp;
+    const unsigned pb = (unsigned)((tot + 255) / 256);
+    const size_t sm_fwd = sizeof(double) * (size_t)(NB * LDB + NB * ldy + KC * LDA);
+    const size_t sm_diag = sizeof(double) * (size_t)(NB * LDB + NB * ldy);
+    const size_t sm_push = sizeof(double) * (size_t)(NB * LDP + 32 * ldy);
+    if (mode == 0) {
+      hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dB, D->W);
+      for (int32_t l = 0; l < S.nlevels; ++l) {
+        const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
+        if (t1 == t0) continue;
+        if (mf)
+          hipLaunchKernelGGL((k_fwd<true, 0>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                             fac->L, fac->invD, (const double*)D->W, D->W, D->X, rp, ldy);
+        else
+          hipLaunchKernelGGL((k_fwd<false, 0>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                             fac->L, fac->invD, (const double*)D->W, D->W, D->X, rp, ldy);
+      }
+      if (!mid_recorded) {
+        HIPCHK(hipEventRecord(D->ev[4], st));
+        mid_recorded = true;
+      }
+      for (int32_t l = S.nlevels - 1; l >= 0; --l) {
+        const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
+        const int64_t p0 = S.level_pair_ptr[l], p1 = S.level_pair_ptr[l + 1];
+        if (f1 > f0) {
+          if (mf)
+            hipLaunchKernelGGL(k_bwd_diag<true>, dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v, D->d_level_fronts + f0,
+                               fac->invD, D->X, rp, ldy);
+          else
+            hipLaunchKernelGGL(k_bwd_diag<false>, dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v, D->d_level_fronts + f0,
+                               fac->invD, D->X, rp, ldy);
+        }
+        if (p1 > p0) {
+          if (mf)
+            hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)(p1 - p0)), dim3(256), sm_push, st, D->v, D->d_level_pairs + p0,
+                               fac->L, D->X, rp, ldy);
+          else
+            hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)(p1 - p0)), dim3(256), sm_push, st, D->v, D->d_level_pairs + p0,
+                               fac->L, D->X, rp, ldy);
+        }
+      }
+      hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
+    } else {
+      // Z = P^T (L R): R is NOT permuted on the way in (SparseCholesky.py:50-51)
+      hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, (const int32_t*)nullptr, dB, D->W);
+      HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, st));
+      if (ntiles_all > 0) {
+        if (mf)
+          hipLaunchKernelGGL((k_fwd<true, 1>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
+                             fac->invD, (const double*)D->W, D->X, D->X, rp, ldy);
+        else
+          hipLaunchKernelGGL((k_fwd<false, 1>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
+                             fac->invD, (const double*)D->W, D->X, D->X, rp, ldy);
+      }
+      hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
+    }
+  }
+  if (!mid_recorded) HIPCHK(hipEventRecord(D->ev[4], st));
+  HIPCHK(hipEventRecord(D->ev[5], st));
+  HIPCHK(hipGetLastError());
+  return SCILMM_OK;
+}
+
+int finish_rhs_timing(scilmm_symbolic* sym, Dev* D, int mode) {
+  float a = 0, b = 0;
+  HIPCHK(hipEventElapsedTime(&a, D->ev[3], D->ev[4]));
+  HIPCHK(hipEventElapsedTime(&b, D->ev[4], D->ev[5]));
+  if (mode == 0) {
+    D->timing.solve_fwd_ms = a;
+    D->timing.solve_bwd_ms = b;
+  } else {
+    D->timing.lmul_ms = a + b;
+  }
+  return SCILMM_OK;
+}
+
+int run_quad(scilmm_symbolic* sym, Dev* D, int32_t k, const double* dU, int32_t r, double* d_out) {
+  const Symbolic& S = *sym->S;
+  if (k < 0 || k >= S.K || !D->have_vals[k]) {
+    sym->err = "quadforms: matrix index invalid or values not uploaded";
+    return SCILMM_ERR_STATE;
+  }
+  int stc = ensure_work(sym, D);
+  if (stc != SCILMM_OK) return stc;
+  hipStream_t st = D->stream;
+  const int64_t SPW = 512;
+  const int64_t nw_gen = ((S.nnz_pattern + SPW - 1) / SPW + 3) / 4 * 4;
+  const int64_t nw_dia = 1024;
+  const int64_t nw = std::max(nw_gen, nw_dia);
+  if (D->nwaves_quad < nw) {
+    if (D->partial) (void)hipFree(D->partial);
+    D->partial = nullptr;
+    HIPCHK(hipMalloc((void**)&D->partial, sizeof(double) * (size_t)nw * RPMAX));
+    D->nwaves_quad = nw;
+  }
+  HIPCHK(hipEventRecord(D->ev[6], st));
+  for (int32_t cbeg = 0; cbeg < r; cbeg += RPMAX) {
+    const int rc = std::min<int>(RPMAX, r - cbeg);
+    const int rp = rp_of(rc);
+    const int64_t tot = (int64_t)S.n * rp;
+    hipLaunchKernelGGL(k_perm_in, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dU, D->W);
+    int64_t nwaves;
+    if (S.is_diag[k]) {
+      nwaves = nw_dia;
+      hipLaunchKernelGGL(k_quad_diag, dim3((unsigned)(nwaves / 4)), dim3(256), 0, st, S.n, (const double*)D->vals[k],
+                         (const double*)D->W, rp, D->partial);
+    } else {
+      nwaves = nw_gen;
+      hipLaunchKernelGGL(k_quad, dim3((unsigned)(nwaves / 4)), dim3(256), 0, st, D->v, S.nnz_pattern, SPW,
+                         (const double*)D->vals[k], (const double*)D->W, rp, D->partial);
+    }
+    hipLaunchKernelGGL(k_quad_reduce, dim3(1), dim3(RPMAX), 0, st, nwaves, (const double*)D->partial, rp, D->d_out, 1.0, 0);
+    HIPCHK(hipMemcpyAsync(d_out + cbeg, D->d_out, sizeof(double) * rc, hipMemcpyDeviceToDevice, st));
+  }
+  HIPCHK(hipEventRecord(D->ev[7], st));
+  HIPCHK(hipGetLastError());
+  return SCILMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) {
+  if (!sym || !sym->S || !data_k) return SCILMM_ERR_ARG;
+  const Symbolic& S = *sym->S;
+  if (k < 0 || k >= S.K) return SCILMM_ERR_ARG;
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  // general matrix: values permuted into pattern-slot order; diagonal-only matrix: one value per
+  // permuted row.  Either way h[val_slot] = data[val_src].
+  std::vector<double> h(S.is_diag[k] ? (size_t)S.n : (size_t)S.nnz_pattern, 0.0);
+  {
+    const auto& slot = S.val_slot[k];
+    const auto& src = S.val_src[k];
+    for (size_t t = 0; t < slot.size(); ++t) h[slot[t]] = data_k[src[t]];
+  }
+  if (!D->vals[k]) HIPCHK(hipMalloc((void**)&D->vals[k], std::max<size_t>(h.size(), 1) * sizeof(double)));
+  if (!h.empty()) HIPCHK(hipMemcpy(D->vals[k], h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  D->have_vals[k] = 1;
+  return SCILMM_OK;
+}
+
+int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor** out, int32_t* bad_col) {
+  if (!sym || !sym->S || !sigma2 || !out) return SCILMM_ERR_ARG;
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  const Symbolic& S = *sym->S;
+  scilmm_factor* f = new scilmm_factor();
+  f->sym = sym;
+  *out = f;
+  HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * (size_t)std::max<int64_t>(S.nnzL_stored, 1)));
+  HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * (size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1)));
+  HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
+  HIPCHK(hipMalloc((void**)&f->status, sizeof(int32_t)));
+  return run_factorize(f, sigma2, bad_col);
+}
+
+int scilmm_refactorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
+  if (!fac || !fac->sym || !sigma2) return SCILMM_ERR_ARG;
+  return run_factorize(fac, sigma2, bad_col);
+}
+
+void scilmm_factor_free(scilmm_factor* fac) {
+  if (!fac) return;
+  if (fac->L) (void)hipFree(fac->L);
+  if (fac->invD) (void)hipFree(fac->invD);
+  if (fac->logd) (void)hipFree(fac->logd);
+  if (fac->status) (void)hipFree(fac->status);
+  delete fac;
+}
+
+int scilmm_logdet(scilmm_factor* fac, double* out) {
+  if (!fac || !fac->sym || !out) return SCILMM_ERR_ARG;
+  scilmm_symbolic* sym = fac->sym;
+  if (!fac->valid) return SCILMM_ERR_STATE;
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  std::vector<double> h(S.nsuper);
+  HIPCHK(hipMemcpyAsync(h.data(), fac->logd, sizeof(double) * S.nsuper, hipMemcpyDeviceToHost, D->stream));
+  HIPCHK(hipStreamSynchronize(D->stream));
+  // fixed-order pairwise-free summation: deterministic
+  long double s = 0.0L;
+  for (double v : h) s += v;
+  *out = (double)(2.0L * s);
+  return SCILMM_OK;
+}
+
+static int host_rhs(scilmm_factor* fac, const double* B, int32_t r, double* X, int mode) {
+  if (!fac || !fac->sym || !B || !X || r <= 0) return SCILMM_ERR_ARG;
+  scilmm_symbolic* sym = fac->sym;
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  const size_t cnt = (size_t)S.n * (size_t)r;
+  int st = ensure_io(sym, D, 2 * cnt);
+  if (st != SCILMM_OK) return st;
+  double* dB = D->IO;
+  double* dX = D->IO + cnt;
+  HIPCHK(hipMemcpyAsync(dB, B, cnt * sizeof(double), hipMemcpyHostToDevice, D->stream));
+  st = run_rhs(fac, dB, r, dX, mode);
+  if (st != SCILMM_OK) return st;
+  HIPCHK(hipMemcpyAsync(X, dX, cnt * sizeof(double), hipMemcpyDeviceToHost, D->stream));
+  HIPCHK(hipStreamSynchronize(D->stream));
+  return finish_rhs_timing(sym, D, mode);
+}
+
+int scilmm_solve(scilmm_factor* fac, const double* B, int32_t r, double* X) { return host_rhs(fac, B, r, X, 0); }
+int scilmm_lmul(scilmm_factor* fac, const double* R, int32_t r, double* Z) { return host_rhs(fac, R, r, Z, 1); }
+
+int scilmm_solve_dev(scilmm_factor* fac, const double* dB, int32_t r, double* dX) {
+  if (!fac || !fac->sym || !dB || !dX || r <= 0) return SCILMM_ERR_ARG;
+  return run_rhs(fac, dB, r, dX, 0);
+}
+int scilmm_lmul_dev(scilmm_factor* fac, const double* dR, int32_t r, double* dZ) {
+  if (!fac || !fac->sym || !dR || !dZ || r <= 0) return SCILMM_ERR_ARG;
+  return run_rhs(fac, dR, r, dZ, 1);
+}
+
+int scilmm_quadforms_dev(scilmm_symbolic* sym, int32_t k, const double* dU, int32_t r, double* d_out) {
+  if (!sym || !sym->S || !dU || !d_out || r <= 0) return SCILMM_ERR_ARG;
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  return run_quad(sym, D, k, dU, r, d_out);
+}
+
+int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r, double* out) {
+  if (!sym || !sym->S || !U || !out || r <= 0) return SCILMM_ERR_ARG;
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  const Symbolic& S = *sym->S;
+  const size_t cnt = (size_t)S.n * (size_t)r;
+  st = ensure_io(sym, D, cnt + (size_t)r);
+  if (st != SCILMM_OK) return st;
+  HIPCHK(hipMemcpyAsync(D->IO, U, cnt * sizeof(double), hipMemcpyHostToDevice, D->stream));
+  st = run_quad(sym, D, k, D->IO, r, D->IO + cnt);
+  if (st != SCILMM_OK) return st;
+  HIPCHK(hipMemcpyAsync(out, D->IO + cnt, sizeof(double) * r, hipMemcpyDeviceToHost, D->stream));
+  HIPCHK(hipStreamSynchronize(D->stream));
+  float q = 0;
+  HIPCHK(hipEventElapsedTime(&q, D->ev[6], D->ev[7]));
+  D->timing.quad_ms = q;
+  return SCILMM_OK;
+}
+
+int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y) {
+  if (!sym || !sym->S || !X || !Y || r <= 0) return SCILMM_ERR_ARG;
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  const Symbolic& S = *sym->S;
+  if (k < 0 || k >= S.K || !D->have_vals[k]) return SCILMM_ERR_STATE;
+  st = ensure_work(sym, D);
+  if (st != SCILMM_OK) return st;
+  const size_t cnt = (size_t)S.n * (size_t)r;
+  st = ensure_io(sym, D, 2 * cnt);
+  if (st != SCILMM_OK) return st;
+  hipStream_t s = D->stream;
+  HIPCHK(hipMemcpyAsync(D->IO, X, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+  for (int32_t cbeg = 0; cbeg < r; cbeg += RPMAX) {
+    const int rc = std::min<int>(RPMAX, r - cbeg);
+    const int rp = rp_of(rc);
+    const int64_t tot = (int64_t)S.n * rp;
+    const unsigned pb = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, s, S.n, r, rp, cbeg, D->v.perm, (const double*)D->IO, D->W);
+    HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, s));
+    if (S.is_diag[k])
+      hipLaunchKernelGGL(k_spmm_diag, dim3(pb), dim3(256), 0, s, S.n, (const double*)D->vals[k], (const double*)D->W, rp, D->X);
+    else
+      hipLaunchKernelGGL(k_spmm, dim3((unsigned)((S.nnz_pattern + 255) / 256)), dim3(256), 0, s, D->v, S.nnz_pattern,
+                         (const double*)D->vals[k], (const double*)D->W, rp, rc, D->X);
+    hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, s, S.n, r, rp, cbeg, D->v.perm, (const double*)D->X, D->IO + cnt);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(Y, D->IO + cnt, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return SCILMM_OK;
+}
+
+int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double* vals, int64_t* nnz) {
+  if (!fac || !fac->sym || !nnz) return SCILMM_ERR_ARG;
+  scilmm_symbolic* sym = fac->sym;
+  const Symbolic& S = *sym->S;
+  int64_t total = 0;
+  for (int32_t s = 0; s < S.nsuper; ++s) {
+    int64_t m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+    int64_t w = S.sn_start[s + 1] - S.sn_start[s];
+    total += m * w - w * (w - 1) / 2;
+  }
+  *nnz = total;
+  if (!vals) return SCILMM_OK;
+  if (!colptr || !rowidx) return SCILMM_ERR_ARG;
+  if (!fac->valid) return SCILMM_ERR_STATE;
+  Dev* D = (Dev*)sym->device;
+  std::vector<double> h((size_t)std::max<int64_t>(S.nnzL_stored, 1));
+  HIPCHK(hipMemcpyAsync(h.data(), fac->L, sizeof(double) * (size_t)S.nnzL_stored, hipMemcpyDeviceToHost, D->stream));
+  HIPCHK(hipStreamSynchronize(D->stream));
+  int64_t p = 0;
+  for (int32_t s = 0; s < S.nsuper; ++s) {
+    const int32_t* rs = S.sn_rows.data() + S.sn_rowptr[s];
+    int64_t m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+    int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+    const double* P = h.data() + S.sn_loff[s];
+    for (int32_t j = 0; j < w; ++j) {
+      colptr[c0 + j] = p;
+      for (int64_t t = j; t < m; ++t) {
+        rowidx[p] = rs[t];
+        vals[p] = P[(int64_t)j * m + t];
+        ++p;
+      }
+    }
+  }
+  colptr[S.n] = p;
+  return SCILMM_OK;
+}
+
+int scilmm_sync(scilmm_symbolic* sym) {
+  if (!sym || !sym->device) return SCILMM_ERR_ARG;
+  Dev* D = (Dev*)sym->device;
+  HIPCHK(hipStreamSynchronize(D->stream));
+  return SCILMM_OK;
+}
+
+int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out) {
+  if (!sym || !sym->device || !out) return SCILMM_ERR_ARG;
+  *out = ((Dev*)sym->device)->timing;
+  return SCILMM_OK;
+}
+
+const char* scilmm_version(void) { return "scilmm_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,694 @@
+// Hand-written CDNA4 (gfx950) kernels of the numeric phase.  Wave = 64 lanes; 256-thread workgroups
+// (one wave per SIMD); fp64 MFMA v_mfma_f64_16x16x4_f64 for every GEMM-shaped step.
+//
+// Data layout in HBM:
+//   L        : supernodal panels, column-major m_s x w_s, leading dimension m_s, at sn_loff[s]
+//   invD     : w_s x w_s inverse of every diagonal block (column-major) at inv_off[s]
+//   vals_k   : A_k values permuted into "pattern slot" order (permuted CSC of tril(union pattern))
+//   W / X    : right-hand sides, PERMUTED row order, row-major n x rp (rp = r rounded up to 16)
+//
+// MFMA operand convention used everywhere (cdna_hip_programming.md §3, f64 note):
+//   D[M][N] += sum_k Aop[M][k] * Bop[k][N];  lane l supplies Aop[l&15][l>>4] and Bop[l>>4][l&15];
+//   lane l receives D[(l>>4) + 4*reg][l&15], reg = 0..3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scilmm {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int NB = 64;        // max supernode block width (symbolic max_width must be <= NB)
+constexpr int TM = 128;       // target rows per tile
+constexpr int KC = 32;        // k-chunk staged through LDS
+constexpr int LDA = TM + 16;  // k-major LDS leading dims: (ld*8 B) == 128 mod 256 -> conflict-free b64 reads
+constexpr int LDB = NB + 16;
+constexpr int RPMAX = 128;    // max padded RHS columns per pass
+constexpr int LDP = 34;       // [k][q] LDS image of a panel slice (q-chunk of 32)
+
+struct DevSym {
+  int32_t n, nsuper;
+  const int32_t* sn_start;
+  const int64_t* sn_rowptr;
+  const int32_t* sn_rows;
+  const int64_t* sn_loff;
+  const int64_t* inv_off;
+  const int32_t* upd_src;
+  const int32_t* upd_p0;
+  const int32_t* upd_p1;
+  const int32_t* tile_front;
+  const int64_t* tile_base;
+  const int64_t* combo_ptr;
+  const int32_t* combo_pair;
+  const int32_t* combo_ta;
+  const int32_t* combo_tb;
+  const int64_t* asm_dst;
+  const int64_t* diag_dst;
+  const int64_t* pat_colptr;
+  const int32_t* pat_row;
+  const int32_t* perm;
+};
+
+struct ValPtrs {
+  const double* v[8];
+  double s2[8];
+  int32_t count;
+};
+
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// V = sum_k s2_k A_k scattered into the (zeroed) panels.  HBM-bound: per pattern entry reads 8 B per
+// general matrix + 8 B map, writes 8 B.
+__global__ void k_assemble(int64_t nnz, const int64_t* __restrict__ dst, ValPtrs vp, double* __restrict__ L) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < vp.count) v += vp.s2[k] * vp.v[k][e];
+    L[dst[e]] = v;
+  }
+}
+
+__global__ void k_add_diag(int32_t n, const int64_t* __restrict__ diag_dst, ValPtrs vp, double* __restrict__ L) {
+  int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double v = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < vp.count) v += vp.s2[k] * vp.v[k][j];
+  L[diag_dst[j]] += v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared MFMA stage: acc[jb][ib] (16 x 16 each) += Bs^T[j][k] * As[k][i] over kc4 staged k values.
+// D[M=j][N=i]; wave wv owns target rows i in [32 wv, 32 wv + 32), all NB columns j.
+template <bool MFMA>
+__device__ __forceinline__ void tile_mma(const double* __restrict__ As, const double* __restrict__ Bs, int kc4, int ncb,
+                                         int lane, int wv, d4 (&acc)[4][2]) {
+  if (MFMA) {
+    const int li = lane & 15, lk = lane >> 4;
+    for (int k4 = 0; k4 < kc4; k4 += 4) {
+      const int kk = k4 + lk;
+      const double b0 = As[kk * LDA + 32 * wv + li];
+      const double b1 = As[kk * LDA + 32 * wv + 16 + li];
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        if (jb < ncb) {
+          const double a = Bs[kk * LDB + 16 * jb + li];
+          acc[jb][0] = mfma_f64(a, b0, acc[jb][0]);
+          acc[jb][1] = mfma_f64(a, b1, acc[jb][1]);
+        }
+      }
+    }
+  } else {
+    // scalar restatement of the same tile product in the same accumulator layout (debug path)
+    const int li = lane & 15, lr = lane >> 4;
+    for (int k = 0; k < kc4; ++k) {
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[jb][ib][r] += Bs[k * LDB + 16 * jb + lr + 4 * r] * As[k * LDA + 32 * wv + 16 * ib + li];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Left-looking supernodal update of one 128-row tile of a target panel:
+//   P_s[tile, :] -= sum over combos (d, rows ta..tb of d)  L_d[ta:tb, :] * L_d[p0:p1, :]^T
+// Rows/columns of each descendant are gathered into TARGET coordinates inside LDS, so the
+// accumulators stay in registers across all descendants.  MFMA-bound for the dense blocks.
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_update(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L) {
+  __shared__ __attribute__((aligned(16))) double As[KC * LDA];
+  __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
+  __shared__ int32_t rowlab[TM];
+  __shared__ int32_t ipos[TM];
+  __shared__ int32_t jpos[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int64_t cb = S.combo_ptr[g], ce = S.combo_ptr[g + 1];
+  if (cb == ce) return;
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  const int ncb = (w + 15) >> 4;
+  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
+  d4 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  __syncthreads();
+  for (int64_t c = cb; c < ce; ++c) {
+    const int32_t e = S.combo_pair[c];
+    const int32_t d = S.upd_src[e], p0 = S.upd_p0[e], p1 = S.upd_p1[e];
+    const int32_t ta = S.combo_ta[c], tb = S.combo_tb[c];
+    const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
+    const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+    const int32_t wd = S.sn_start[d + 1] - S.sn_start[d];
+    const double* Pd = L + S.sn_loff[d];
+    const int32_t nt = tb - ta, nq = p1 - p0;
+    __syncthreads();  // previous combo's compute is done with ipos/jpos/As/Bs
+    if (tid < nt) {
+      const int32_t lab = rd[ta + tid];
+      int lo = 0, hi = nrow;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
+      }
+      ipos[tid] = lo;
+    } else if (tid >= 128 && tid - 128 < nq) {
+      jpos[tid - 128] = rd[p0 + tid - 128] - c0;
+    }
+    const bool fullA = (nt == nrow), fullB = (nq == w);
+    for (int32_t k0 = 0; k0 < wd; k0 += KC) {
+      const int kc = min(KC, wd - k0);
+      const int kc4 = (kc + 3) & ~3;
+      if (k0 > 0) __syncthreads();  // compute of the previous chunk finished
+      // rows of the LDS images that this chunk does not overwrite must read as zero
+      if (!fullA) {
+        for (int idx = tid; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
+      } else {
+        for (int idx = tid + kc * LDA; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
+      }
+      if (!fullB) {
+        for (int idx = tid; idx < kc4 * LDB; idx += 256) Bs[idx] = 0.0;
+      } else {
+        for (int idx = tid + kc * LDB; idx < kc4 * LDB; idx += 256) Bs[idx] = 0.0;
+      }
+      __syncthreads();
+      {
+        const int t = tid & 127;
+        if (t < nt) {
+          const int ip = ipos[t];
+          for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + ip] = Pd[(int64_t)(k0 + k) * md + ta + t];
+        }
+        const int q = tid & 63;
+        if (q < nq) {
+          const int jp = jpos[q];
+          for (int k = tid >> 6; k < kc; k += 4) Bs[k * LDB + jp] = Pd[(int64_t)(k0 + k) * md + p0 + q];
+        }
+      }
+      __syncthreads();
+      if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
+    }
+  }
+  // epilogue: D[M=j][N=i] -> panel(R0+i, j); 16 consecutive lanes hit 128 contiguous bytes of a column
+  double* P = L + S.sn_loff[s];
+  const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 32 * wv + 16 * ib + li;
+        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][ib][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense Cholesky of the w x w diagonal block of each front of a level, in LDS, plus its explicit
+// inverse (so every later triangular solve with this block is an MFMA GEMM) and sum(log diag).
+__global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
+                                               double* __restrict__ invD, double* __restrict__ logd,
+                                               int32_t* __restrict__ status) {
+  constexpr int LD = NB + 1;
+  __shared__ double Ls[NB * LD];
+  __shared__ double Xs[NB * LD];
+  const int tid = threadIdx.x;
+  const int32_t s = fronts[blockIdx.x];
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  double* P = L + S.sn_loff[s];
+  for (int idx = tid; idx < w * w; idx += 256) {
+    const int k = idx / w, i = idx - k * w;
+    Ls[i * LD + k] = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
+    Xs[i * LD + k] = 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < w; ++j) {
+    if (tid == 0) {
+      double dj = Ls[j * LD + j];
+      if (!(dj > 0.0) || !(dj < 1.0e300)) {
+        atomicMin(status, c0 + j);
+        dj = 1.0;
+      }
+      Ls[j * LD + j] = sqrt(dj);
+    }
+    __syncthreads();
+    const double inv = 1.0 / Ls[j * LD + j];
+    for (int i = j + 1 + tid; i < w; i += 256) Ls[i * LD + j] *= inv;
+    __syncthreads();
+    const int nrem = w - j - 1;
+    for (int idx = tid; idx < nrem * nrem; idx += 256) {
+      const int ii = idx / nrem, kk = idx - ii * nrem;
+      if (kk <= ii) {
+        const int i = j + 1 + ii, k = j + 1 + kk;
+        Ls[i * LD + k] -= Ls[i * LD + j] * Ls[k * LD + j];
+      }
+    }
+    __syncthreads();
+  }
+  // inverse of the lower-triangular block: thread c owns column c (uniform loops => broadcast reads)
+  if (tid < w) {
+    const int c = tid;
+    for (int j = 0; j < w; ++j) {
+      double sum = (j == c) ? 1.0 : 0.0;
+      for (int k = 0; k < j; ++k) sum -= Ls[j * LD + k] * Xs[k * LD + c];
+      Xs[j * LD + c] = (j >= c) ? sum / Ls[j * LD + j] : 0.0;
+    }
+  }
+  if (tid == 64) {
+    double sl = 0.0;
+    for (int j = 0; j < w; ++j) sl += log(Ls[j * LD + j]);
+    logd[s] = sl;
+  }
+  __syncthreads();
+  double* I = invD + S.inv_off[s];
+  for (int idx = tid; idx < w * w; idx += 256) {
+    const int k = idx / w, i = idx - k * w;
+    P[(int64_t)k * m + i] = Ls[i * LD + k];  // upper part was zeroed on load
+    I[k * w + i] = Xs[i * LD + k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sub-diagonal panel solve as a GEMM with the inverse diagonal block:
+//   P[i, :] <- P[i, :] * invL^T   for the rows i >= w of a 128-row tile.   D[M=j][N=i].
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
+                                              const double* __restrict__ invD) {
+  __shared__ __attribute__((aligned(16))) double As[KC * LDA];
+  __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  if (R0 + nrow <= w) return;  // tile lies entirely inside the diagonal block
+  const int ncb = (w + 15) >> 4;
+  double* P = L + S.sn_loff[s];
+  const double* I = invD + S.inv_off[s];
+  d4 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int32_t k0 = 0; k0 < w; k0 += KC) {
+    const int kc = min(KC, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (k0 > 0) __syncthreads();
+    for (int idx = tid + kc * LDA; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
+    for (int idx = tid; idx < kc4 * LDB; idx += 256) Bs[idx] = 0.0;
+    __syncthreads();
+    {
+      const int t = tid & 127;
+      if (t < nrow)
+        for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + t] = P[(int64_t)(k0 + k) * m + R0 + t];
+      const int q = tid & 63;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
+      if (q < w)
+        for (int k = tid >> 6; k < kc; k += 4) Bs[k * LDB + q] = I[(k0 + k) * w + q];
+    }
+    __syncthreads();
+    if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
+  }
+  const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 32 * wv + 16 * ib + li;
+        if (i < nrow && R0 + i >= w && j < w) P[(int64_t)j * m + R0 + i] = acc[jb][ib][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Right-hand-side kernels.  rp = padded column count (multiple of 16, <= RPMAX); ldy = LDS leading
+// dimension of [k][c] images (== 16 mod 32 so that b64 reads of Bop[k][c] are conflict-free).
+
+__global__ void k_perm_in(int32_t n, int32_t r, int32_t rp, int32_t cbeg, const int32_t* __restrict__ perm,
+                          const double* __restrict__ B, double* __restrict__ W) {
+  // W[p][c] = B[perm[p]][cbeg + c]   (perm == nullptr: identity, only pads the columns)
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * rp) return;
+  int32_t p = (int32_t)(idx / rp), c = (int32_t)(idx - (int64_t)p * rp);
+  const int32_t src = perm ? perm[p] : p;
+  W[idx] = (cbeg + c < r) ? B[(int64_t)src * r + cbeg + c] : 0.0;
+}
+
+__global__ void k_perm_out(int32_t n, int32_t r, int32_t rp, int32_t cbeg, const int32_t* __restrict__ perm,
+                           const double* __restrict__ Xp, double* __restrict__ X) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * rp) return;
+  int32_t p = (int32_t)(idx / rp), c = (int32_t)(idx - (int64_t)p * rp);
+  if (cbeg + c < r) X[(int64_t)perm[p] * r + cbeg + c] = Xp[idx];
+}
+
+// D[M][N=c] accumulate helper for RHS kernels: one M-tile (16 rows) x ncn N-tiles (16 cols each).
+// Aop[M=row][k] read from a k-major image A_lds[k*lda + row0 + (l&15)], Bop[k][c] from Y_lds[k*ldy + c].
+template <bool MFMA, int NCT>
+__device__ __forceinline__ void rhs_mma(const double* __restrict__ A_lds, int lda, int row0,
+                                        const double* __restrict__ Y_lds, int ldy, int kn4, int ncn, int lane,
+                                        d4 (&acc)[NCT]) {
+  const int li = lane & 15, lk = lane >> 4;
+  if (MFMA) {
+    for (int k4 = 0; k4 < kn4; k4 += 4) {
+      const double a = A_lds[(k4 + lk) * lda + row0 + li];
+#pragma unroll
+      for (int cn = 0; cn < NCT; ++cn)
+        if (cn < ncn) acc[cn] = mfma_f64(a, Y_lds[(k4 + lk) * ldy + 16 * cn + li], acc[cn]);
+    }
+  } else {
+    for (int k = 0; k < kn4; ++k)
+#pragma unroll
+      for (int cn = 0; cn < NCT; ++cn)
+        if (cn < ncn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[cn][r] += A_lds[k * lda + row0 + lk + 4 * r] * Y_lds[k * ldy + 16 * cn + li];
+  }
+}
+
+// Forward sweep of one level (push form).  Workgroup = (front s, 128-row tile):
+//   x_s = invL_s * W[c0:c1, :]            (every tile recomputes it; tile 0 publishes it to Xout)
+//   W[rows below] -= L21[tile rows, :] * x_s   through fp64 hardware atomics (rows of higher levels).
+// MODE 0: forward solve.  MODE 1: multiply (Z += L[:, s] * R_s, including the diagonal block).
+template <bool MFMA, int MODE>
+__global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
+                                             const double* __restrict__ invD, const double* Yin, double* W,
+                                             double* Xout, int32_t rp, int32_t ldy) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Is = smem;                 // [NB][LDB]   invL as Aop source: Is[k*LDB + j] = invL[j][k]
+  double* Ys = Is + NB * LDB;        // [NB][ldy]   y then x
+  double* As = Ys + NB * ldy;        // [KC][LDA]   panel chunk
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  if (MODE == 0 && ti > 0 && R0 + nrow <= w) return;
+  const int ncn = rp >> 4;
+  const int w4 = (w + 3) & ~3;
+  const double* P = L + S.sn_loff[s];
+  // stage y_s (and invL for the solve)
+  for (int idx = tid; idx < w4 * ldy; idx += 256) {
+    const int k = idx / ldy, c = idx - k * ldy;
+    Ys[idx] = (k < w && c < rp) ? Yin[(int64_t)(c0 + k) * rp + c] : 0.0;
+  }
+  if (MODE == 0) {
+    const double* I = invD + S.inv_off[s];
+    for (int idx = tid; idx < w4 * LDB; idx += 256) {
+      const int k = idx / LDB, j = idx - k * LDB;
+      Is[idx] = (k < w && j < w) ? I[k * w + j] : 0.0;
+    }
+    __syncthreads();
+    // x = invL * y : wave wv owns rows j in [16 wv, 16 wv + 16)
+    d4 xa[RPMAX / 16];
+#pragma unroll
+    for (int cn = 0; cn < RPMAX / 16; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (16 * wv < w) rhs_mma<MFMA, RPMAX / 16>(Is, LDB, 16 * wv, Ys, ldy, w4, ncn, lane, xa);
+    __syncthreads();
+    if (16 * wv < w) {
+      const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+      for (int cn = 0; cn < RPMAX / 16; ++cn)
+        if (cn < ncn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * wv + lr + 4 * r;
+            Ys[j * ldy + 16 * cn + li] = (j < w) ? xa[cn][r] : 0.0;
+            if (ti == 0 && j < w) Xout[(int64_t)(c0 + j) * rp + 16 * cn + li] = xa[cn][r];
+          }
+    }
+  }
+  __syncthreads();
+  if (MODE == 0 && R0 + nrow <= w) return;
+  // acc[i][c] = sum_k P[R0+i][k] * x[k][c]; wave wv owns rows [32 wv, 32 wv + 32)
+  d4 a0[RPMAX / 16], a1[RPMAX / 16];
+#pragma unroll
+  for (int cn = 0; cn < RPMAX / 16; ++cn) {
+    a0[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+    a1[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+  for (int32_t k0 = 0; k0 < w; k0 += KC) {
+    const int kc = min(KC, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (k0 > 0) __syncthreads();
+    {
+      const int t = tid & 127;
+      for (int k = tid >> 7; k < kc4; k += 2)
+        As[k * LDA + t] = (t < nrow && k < kc) ? P[(int64_t)(k0 + k) * m + R0 + t] : 0.0;
+    }
+    __syncthreads();
+    if (32 * wv < nrow) {
+      rhs_mma<MFMA, RPMAX / 16>(As, LDA, 32 * wv, Ys + k0 * ldy, ldy, kc4, ncn, lane, a0);
+      if (32 * wv + 16 < nrow) rhs_mma<MFMA, RPMAX / 16>(As, LDA, 32 * wv + 16, Ys + k0 * ldy, ldy, kc4, ncn, lane, a1);
+    }
+  }
+  const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+  for (int cn = 0; cn < RPMAX / 16; ++cn)
+    if (cn < ncn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = 32 * wv + lr + 4 * r;
+        if (i < nrow && (MODE == 1 || R0 + i >= w)) {
+          double v = a0[cn][r];
+          unsafeAtomicAdd(&W[(int64_t)rs[R0 + i] * rp + 16 * cn + li], MODE == 0 ? -v : v);
+        }
+        i += 16;
+        if (i < nrow && (MODE == 1 || R0 + i >= w)) {
+          double v = a1[cn][r];
+          unsafeAtomicAdd(&W[(int64_t)rs[R0 + i] * rp + 16 * cn + li], MODE == 0 ? -v : v);
+        }
+      }
+}
+
+// Backward sweep, step (a): x_s = invL_s^T * y_s in place on X rows c0..c1 (one workgroup per front).
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_bwd_diag(DevSym S, const int32_t* __restrict__ fronts,
+                                                  const double* __restrict__ invD, double* __restrict__ X, int32_t rp,
+                                                  int32_t ldy) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Is = smem;           // Is[k*LDB + j] = invL[k][j]  (Aop[j][k] = invL^T[j][k])
+  double* Ys = Is + NB * LDB;  // [NB][ldy]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t s = fronts[blockIdx.x];
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int ncn = rp >> 4;
+  const int w4 = (w + 3) & ~3;
+  const double* I = invD + S.inv_off[s];
+  for (int idx = tid; idx < w4 * ldy; idx += 256) {
+    const int k = idx / ldy, c = idx - k * ldy;
+    Ys[idx] = (k < w && c < rp) ? X[(int64_t)(c0 + k) * rp + c] : 0.0;
+  }
+  for (int idx = tid; idx < w4 * LDB; idx += 256) {
+    const int k = idx / LDB, j = idx - k * LDB;
+    Is[idx] = (k < w && j < w) ? I[j * w + k] : 0.0;  // element (k, j) of the column-major inverse
+  }
+  __syncthreads();
+  d4 xa[RPMAX / 16];
+#pragma unroll
+  for (int cn = 0; cn < RPMAX / 16; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  if (16 * wv < w) {
+    rhs_mma<MFMA, RPMAX / 16>(Is, LDB, 16 * wv, Ys, ldy, w4, ncn, lane, xa);
+    const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+    for (int cn = 0; cn < RPMAX / 16; ++cn)
+      if (cn < ncn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * wv + lr + 4 * r;
+          if (j < w) X[(int64_t)(c0 + j) * rp + 16 * cn + li] = xa[cn][r];
+        }
+  }
+}
+
+// Backward sweep, step (b): for every update pair (target s in this level, descendant d)
+//   X[cols of d] -= L_d[p0:p1, :]^T * X[rows p0..p1 of d]      (those rows are columns of s: final)
+// Two fronts of one level never share a descendant (they would be on one root path), so the
+// read-modify-write of X[cols of d] is exclusive: plain loads/stores, bitwise reproducible.
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __restrict__ pairs,
+                                                  const double* __restrict__ L, double* __restrict__ X, int32_t rp,
+                                                  int32_t ldy) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ps = smem;             // [NB][LDP]  Ps[k*LDP + q] = L_d[p0+q0+q][k]
+  double* Xg = Ps + NB * LDP;    // [32][ldy]  gathered X rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t e = pairs[blockIdx.x];
+  const int32_t d = S.upd_src[e], p0 = S.upd_p0[e], p1 = S.upd_p1[e];
+  const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
+  const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+  const int32_t cd = S.sn_start[d], wd = S.sn_start[d + 1] - cd;
+  const double* Pd = L + S.sn_loff[d];
+  const int ncn = rp >> 4;
+  d4 acc[RPMAX / 16];
+#pragma unroll
+  for (int cn = 0; cn < RPMAX / 16; ++cn) acc[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int32_t q0 = p0; q0 < p1; q0 += 32) {
+    const int qn = min(32, p1 - q0);
+    const int qn4 = (qn + 3) & ~3;
+    if (q0 > p0) __syncthreads();
+    {
+      const int q = tid & 31;
+      for (int k = tid >> 5; k < NB; k += 8)
+        Ps[k * LDP + q] = (q < qn && k < wd) ? Pd[(int64_t)k * md + q0 + q] : 0.0;
+      for (int idx = tid; idx < qn4 * ldy; idx += 256) {
+        const int q2 = idx / ldy, c = idx - q2 * ldy;
+        Xg[idx] = (q2 < qn && c < rp) ? X[(int64_t)rd[q0 + q2] * rp + c] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (16 * wv < wd) {
+      // D[M=k][N=c] += sum_q Ps[k][q] * Xg[q][c];  Aop[k][q] read as Ps[(16 wv + l&15)*LDP + q4 + (l>>4)]
+      const int li = lane & 15, lk = lane >> 4;
+      if (MFMA) {
+        for (int q4 = 0; q4 < qn4; q4 += 4) {
+          const double a = Ps[(16 * wv + li) * LDP + q4 + lk];
+#pragma unroll
+          for (int cn = 0; cn < RPMAX / 16; ++cn)
+            if (cn < ncn) acc[cn] = mfma_f64(a, Xg[(q4 + lk) * ldy + 16 * cn + li], acc[cn]);
+        }
+      } else {
+        for (int q = 0; q < qn4; ++q)
+#pragma unroll
+          for (int cn = 0; cn < RPMAX / 16; ++cn)
+            if (cn < ncn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[cn][r] += Ps[(16 * wv + lk + 4 * r) * LDP + q] * Xg[q * ldy + 16 * cn + li];
+      }
+    }
+  }
+  if (16 * wv < wd) {
+    const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+    for (int cn = 0; cn < RPMAX / 16; ++cn)
+      if (cn < ncn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * wv + lr + 4 * r;
+          if (k < wd) X[(int64_t)(cd + k) * rp + 16 * cn + li] -= acc[cn][r];
+        }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[c] = sum over pattern entries a_ij U[i][c] U[j][c] (x2 off the diagonal): the SpMM+reduce of the
+// stochastic gradient (reference compute_gradients, SparseCholesky.py:65).  Each wave walks a contiguous
+// range of pattern slots; lanes own RHS columns c and c+64.  HBM/L2-bound gather of U rows.
+__global__ __launch_bounds__(256) void k_quad(DevSym S, int64_t nnz, int64_t slots_per_wave,
+                                              const double* __restrict__ vals, const double* __restrict__ U,
+                                              int32_t rp, double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t e0 = wave * slots_per_wave;
+  const int64_t e1 = min(nnz, e0 + slots_per_wave);
+  double t0 = 0.0, t1 = 0.0;
+  if (e0 < e1) {
+    // column containing slot e0
+    int32_t lo = 0, hi = S.n;
+    while (lo < hi) {
+      int32_t mid = (lo + hi) >> 1;
+      if (S.pat_colptr[mid + 1] <= e0) lo = mid + 1; else hi = mid;
+    }
+    int32_t j = lo;
+    int64_t cend = S.pat_colptr[j + 1];
+    const bool h0 = lane < rp, h1 = lane + 64 < rp;
+    double uj0 = h0 ? U[(int64_t)j * rp + lane] : 0.0, uj1 = h1 ? U[(int64_t)j * rp + lane + 64] : 0.0;
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t e = e0; e < e1; ++e) {
+      if (e >= cend) {
+        t0 += uj0 * a0;
+        t1 += uj1 * a1;
+        a0 = a1 = 0.0;
+        while (e >= cend) { ++j; cend = S.pat_colptr[j + 1]; }
+        uj0 = h0 ? U[(int64_t)j * rp + lane] : 0.0;
+        uj1 = h1 ? U[(int64_t)j * rp + lane + 64] : 0.0;
+      }
+      const int32_t i = S.pat_row[e];
+      const double a = (i == j) ? vals[e] : 2.0 * vals[e];
+      if (h0) a0 += a * U[(int64_t)i * rp + lane];
+      if (h1) a1 += a * U[(int64_t)i * rp + lane + 64];
+    }
+    t0 += uj0 * a0;
+    t1 += uj1 * a1;
+  }
+  partial[wave * RPMAX + lane] = t0;
+  partial[wave * RPMAX + lane + 64] = t1;
+}
+
+__global__ void k_quad_reduce(int64_t nwaves, const double* __restrict__ partial, int32_t rp, double* __restrict__ out,
+                              double scale, int accumulate) {
+  const int c = threadIdx.x;
+  if (c >= rp) return;
+  double s = 0.0;
+  for (int64_t w = 0; w < nwaves; ++w) s += partial[w * RPMAX + c];
+  out[c] = (accumulate ? out[c] : 0.0) + scale * s;
+}
+
+// diagonal matrix: out[c] = sum_j d_j U[j][c]^2 ; one workgroup, fixed summation order
+__global__ __launch_bounds__(256) void k_quad_diag(int32_t n, const double* __restrict__ dvals,
+                                                   const double* __restrict__ U, int32_t rp, double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  double t0 = 0.0, t1 = 0.0;
+  for (int64_t j = wave; j < n; j += nw) {
+    const double dj = dvals[j];
+    if (lane < rp) { double u = U[j * rp + lane]; t0 += dj * u * u; }
+    if (lane + 64 < rp) { double u = U[j * rp + lane + 64]; t1 += dj * u * u; }
+  }
+  partial[wave * RPMAX + lane] = t0;
+  partial[wave * RPMAX + lane + 64] = t1;
+}
+
+// Y = A X for few columns (symmetric half stored): used by the REML trace term and the Hessian.
+__global__ void k_spmm(DevSym S, int64_t nnz, const double* __restrict__ vals, const double* __restrict__ X, int32_t rp,
+                       int32_t r, double* __restrict__ Y) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  int32_t lo = 0, hi = S.n;
+  while (lo < hi) {
+    int32_t mid = (lo + hi) >> 1;
+    if (S.pat_colptr[mid + 1] <= e) lo = mid + 1; else hi = mid;
+  }
+  const int32_t j = lo, i = S.pat_row[e];
+  const double a = vals[e];
+  if (a == 0.0) return;
+  for (int c = 0; c < r; ++c) {
+    unsafeAtomicAdd(&Y[(int64_t)i * rp + c], a * X[(int64_t)j * rp + c]);
+    if (i != j) unsafeAtomicAdd(&Y[(int64_t)j * rp + c], a * X[(int64_t)i * rp + c]);
+  }
+}
+
+__global__ void k_spmm_diag(int32_t n, const double* __restrict__ dvals, const double* __restrict__ X, int32_t rp,
+                            double* __restrict__ Y) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * rp) return;
+  Y[idx] += dvals[idx / rp] * X[idx];
+}
+
+}  // namespace scilmm

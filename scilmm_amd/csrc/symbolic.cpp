@@ -85,19 +85,21 @@ int32_t find_root(std::vector<int32_t>& anc, int32_t x) {
   return r;
 }
 
-// Skeleton column counts; labels are already postordered (post = identity).
-// cptr/cidx: for each column j the rows i > j with A_ij != 0.
-void column_counts(int32_t n, const std::vector<int32_t>& parent, const std::vector<int64_t>& cptr,
-                   const std::vector<int32_t>& cidx, std::vector<int32_t>& cc) {
-  std::vector<int32_t> first(n), size(n, 1);
-  for (int32_t j = 0; j < n; ++j)
-    if (parent[j] != -1) size[parent[j]] += size[j];
-  for (int32_t j = 0; j < n; ++j) first[j] = j - size[j] + 1;
+// Skeleton column counts for an arbitrary (topologically valid) labelling; post[k] = k-th node of a
+// postorder of the etree.  cptr/cidx: for each column j the rows i > j with A_ij != 0.
+void column_counts(int32_t n, const std::vector<int32_t>& parent, const std::vector<int32_t>& post,
+                   const std::vector<int64_t>& cptr, const std::vector<int32_t>& cidx, std::vector<int32_t>& cc) {
+  std::vector<int32_t> first(n, -1);
   std::vector<int64_t> delta(n);
-  for (int32_t j = 0; j < n; ++j) delta[j] = (size[j] == 1) ? 1 : 0;
+  for (int32_t k = 0; k < n; ++k) {
+    int32_t j = post[k];
+    delta[j] = (first[j] == -1) ? 1 : 0;  // leaf of the etree
+    for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
+  }
   std::vector<int32_t> maxfirst(n, -1), prevleaf(n, -1), anc(n);
   std::iota(anc.begin(), anc.end(), 0);
-  for (int32_t j = 0; j < n; ++j) {
+  for (int32_t k = 0; k < n; ++k) {
+    const int32_t j = post[k];
     if (parent[j] != -1) delta[parent[j]]--;
     for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
       int32_t i = cidx[e];
@@ -115,7 +117,8 @@ void column_counts(int32_t n, const std::vector<int32_t>& parent, const std::vec
     if (parent[j] != -1) anc[j] = parent[j];
   }
   cc.resize(n);
-  for (int32_t j = 0; j < n; ++j) {
+  for (int32_t k = 0; k < n; ++k) {
+    const int32_t j = post[k];
     cc[j] = (int32_t)delta[j];
     if (parent[j] != -1) delta[parent[j]] += delta[j];
   }
@@ -244,7 +247,9 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   etree(n, rptr, ridx, parent);
   std::vector<int32_t> post;
   postorder(n, parent, post);
-  {
+  // A user-supplied permutation is honoured exactly (parity with an oracle factor of the same P);
+  // otherwise the ordering is composed with the etree postorder (same fill, contiguous supernodes).
+  if (opts.ordering != 2) {
     std::vector<int32_t> perm2(n), pinv(n);
     for (int32_t k = 0; k < n; ++k) {
       perm2[k] = perm[post[k]];
@@ -257,6 +262,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
     build_csc(iperm, cptr, cidx);
     transpose_pattern(n, cptr, cidx, rptr, ridx);
+    std::iota(post.begin(), post.end(), 0);
   }
   S->perm = perm;
   S->iperm = iperm;
@@ -264,7 +270,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 
   // ---------------------------------------------------------------- 5. column counts
   std::vector<int32_t> cc;
-  column_counts(n, parent, cptr, cidx, cc);
+  column_counts(n, parent, post, cptr, cidx, cc);
   S->colcount = cc;
   S->nnzL = 0;
   S->flops = 0;
@@ -410,6 +416,18 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     for (int32_t j = 0; j < n; ++j) slot_ptr[j + 1] = slot_ptr[j] + 1 + (cptr[j + 1] - cptr[j]);
     S->asm_dst.resize(slot_ptr[n]);
     S->diag_dst.resize(n);
+    S->pat_colptr = slot_ptr;
+    S->pat_row.resize(slot_ptr[n]);
+    for (int32_t j = 0; j < n; ++j) {
+      int64_t sl = slot_ptr[j];
+      S->pat_row[sl++] = j;
+      for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) S->pat_row[sl++] = cidx[e];
+    }
+    S->inv_off.assign(ns + 1, 0);
+    for (int32_t s = 0; s < ns; ++s) {
+      int64_t w = out[s].end - out[s].start;
+      S->inv_off[s + 1] = S->inv_off[s] + ((w * w + 1) & ~(int64_t)1);
+    }
     std::vector<int32_t> pos(n, -1);
     for (int32_t s = 0; s < ns; ++s) {
       int64_t rb = S->sn_rowptr[s], re = S->sn_rowptr[s + 1];
@@ -428,7 +446,14 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     S->val_slot.resize(K);
     S->val_src.resize(K);
     for (int32_t k = 0; k < K; ++k) {
-      if (S->is_diag[k]) continue;
+      if (S->is_diag[k]) {
+        for (int32_t i = 0; i < n; ++i)
+          for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+            S->val_slot[k].push_back(iperm[i]);
+            S->val_src[k].push_back(e);
+          }
+        continue;
+      }
       int64_t cntk = 0;
       for (int32_t i = 0; i < n; ++i)
         for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)

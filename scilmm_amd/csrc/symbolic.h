@@ -68,6 +68,9 @@ struct Symbolic {
   int64_t nnz_pattern = 0;        // entries of tril(union pattern)
   std::vector<int64_t> asm_dst;   // [nnz_pattern]
   std::vector<int64_t> diag_dst;  // [n] L offset of each diagonal entry (permuted order)
+  std::vector<int64_t> pat_colptr; // [n+1] pattern slots of permuted column j (diagonal first)
+  std::vector<int32_t> pat_row;    // [nnz_pattern] permuted row label of each slot
+  std::vector<int64_t> inv_off;    // [nsuper+1] offsets of the w x w inverse diagonal blocks
   // per input matrix k: for each stored lower entry (CSR order, j<=i) the pattern slot it lands in
   // (so values_upload can permute data_k into pattern order); empty for diagonal-only matrices
   std::vector<std::vector<int64_t>> val_slot;   // [K][nnz_lower_k]

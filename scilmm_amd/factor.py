@@ -1,0 +1,173 @@
+"""Python handles over the C-ABI (include/scilmm_hip.h): ``Symbolic`` (pattern analysis + device-resident
+A_k values) and ``Factor`` (numeric factor with the reference's factor protocol).
+
+Factor protocol mirrored from what the reference touches on an sksparse Factor
+(reference scilmm/SparseCholesky.py:30,32,40,50,52,93,100; scilmm/Estimation/LMM.py:28,30,38,48-50,87,94):
+``factor(b)``, ``factor.L()``, ``factor.P()``, ``factor.logdet()`` -- plus ``factor.lmul(R)``, the fused
+form of ``factor.L().dot(R)[argsort(P)]`` that never materialises L on the host.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+_ORDERINGS = {"amd": 0, "natural": 1, "given": 2}
+
+
+def _as_csr(m):
+    m = sp.csr_matrix(m)
+    if not m.has_sorted_indices:
+        m = m.sorted_indices()
+    return m
+
+
+class Symbolic(object):
+    """Symbolic analysis of the pattern of V = sum_k s2_k mats[k]; built once, reused for every sigma2."""
+
+    def __init__(self, mats, perm=None, ordering="amd", upload=True, **opts):
+        mats = [_as_csr(m) for m in mats]
+        self.n = n = mats[0].shape[0]
+        for m in mats:
+            if m.shape != (n, n):
+                raise ValueError("all matrices must be square and of equal shape")
+        self.K = K = len(mats)
+        self._indptr = [np.ascontiguousarray(m.indptr, dtype=np.int64) for m in mats]
+        self._indices = [np.ascontiguousarray(m.indices, dtype=np.int32) for m in mats]
+        self._data = [np.ascontiguousarray(m.data, dtype=np.float64) for m in mats]
+        if perm is not None:
+            ordering = "given"
+            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            if perm.shape != (n,):
+                raise ValueError("perm must have length n")
+        o = _lib.Options.default(_ORDERINGS[ordering], **opts)
+        a = (C.c_void_p * K)(*[x.ctypes.data for x in self._indptr])
+        b = (C.c_void_p * K)(*[x.ctypes.data for x in self._indices])
+        h = C.c_void_p()
+        st = lib().scilmm_symbolic_create(n, K, a, b, None if perm is None else ptr(perm), C.byref(o), 1, C.byref(h))
+        self._h = h
+        check(st, h)
+        self._uploaded = False
+        if upload:
+            self.upload_values()
+
+    def upload_values(self):
+        for k in range(self.K):
+            check(lib().scilmm_values_upload(self._h, k, ptr(self._data[k])), self._h)
+        self._uploaded = True
+
+    def set_values(self, k, data):
+        """Replace the values of matrix k (same pattern)."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.shape != self._data[k].shape:
+            raise ValueError("value array does not match the analysed pattern")
+        self._data[k] = data
+        check(lib().scilmm_values_upload(self._h, k, ptr(data)), self._h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().scilmm_symbolic_free(h)
+            self._h = None
+
+    def info(self):
+        info = _lib.Info()
+        check(lib().scilmm_symbolic_info(self._h, C.byref(info)), self._h)
+        return info
+
+    def get(self, name):
+        return _lib.symbolic_get(self._h, name)
+
+    def arrays(self):
+        names = ["perm", "sn_start", "sn_rowptr", "sn_rows", "sn_loff", "upd_ptr", "upd_src", "upd_p0", "upd_p1",
+                 "asm_dst", "diag_dst"]
+        return {k: self.get(k) for k in names}
+
+    def P(self):
+        return self.get("perm").astype(np.int64)
+
+    def factorize(self, sigma2):
+        return Factor(self, sigma2)
+
+    def quadforms(self, k, U):
+        """out[c] = sum_i (A_k U)_ic U_ic  (compute_gradients, SparseCholesky.py:65)."""
+        U = np.ascontiguousarray(np.asarray(U, dtype=np.float64).reshape(self.n, -1))
+        out = np.empty(U.shape[1])
+        check(lib().scilmm_quadforms(self._h, k, ptr(U), U.shape[1], ptr(out)), self._h)
+        return out
+
+    def spmm(self, k, X):
+        X = np.asarray(X, dtype=np.float64)
+        X2 = np.ascontiguousarray(X.reshape(self.n, -1))
+        Y = np.empty_like(X2)
+        check(lib().scilmm_spmm(self._h, k, ptr(X2), X2.shape[1], ptr(Y)), self._h)
+        return Y.reshape(X.shape)
+
+    def timing(self):
+        t = _lib.Timing()
+        check(lib().scilmm_last_timing(self._h, C.byref(t)), self._h)
+        return {f: getattr(t, f) for f, _ in _lib.Timing._fields_}
+
+
+class Factor(object):
+    """Numeric factor L L^T = V[P][:,P] living in HBM."""
+
+    def __init__(self, symbolic, sigma2):
+        self.sym = symbolic
+        self.n = symbolic.n
+        s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
+        if s2.shape != (symbolic.K,):
+            raise ValueError("sigma2 must have one entry per matrix")
+        h = C.c_void_p()
+        bad = C.c_int32(-1)
+        st = lib().scilmm_factorize(symbolic._h, ptr(s2), C.byref(h), C.byref(bad))
+        self._h = h
+        check(st, symbolic._h, bad.value)
+
+    def refactorize(self, sigma2):
+        s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
+        bad = C.c_int32(-1)
+        check(lib().scilmm_refactorize(self._h, ptr(s2), C.byref(bad)), self.sym._h, bad.value)
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().scilmm_factor_free(h)
+            self._h = None
+
+    def _rhs(self, fn, b):
+        b = np.asarray(b, dtype=np.float64)
+        if b.shape[0] != self.n:
+            raise ValueError("right-hand side has %d rows, expected %d" % (b.shape[0], self.n))
+        B = np.ascontiguousarray(b.reshape(self.n, -1))
+        X = np.empty_like(B)
+        check(fn(self._h, ptr(B), B.shape[1], ptr(X)), self.sym._h)
+        return X.reshape(b.shape)
+
+    def __call__(self, b):
+        """factor(b) = V^{-1} b for b of shape (n,) or (n, r)."""
+        return self._rhs(lib().scilmm_solve, b)
+
+    def lmul(self, R):
+        """(factor.L() @ R)[argsort(factor.P())] without exporting L (simulate_vector, SparseCholesky.py:50-51)."""
+        return self._rhs(lib().scilmm_lmul, R)
+
+    def logdet(self):
+        out = C.c_double(0.0)
+        check(lib().scilmm_logdet(self._h, C.byref(out)), self.sym._h)
+        return out.value
+
+    def P(self):
+        return self.sym.P()
+
+    def L(self):
+        nnz = C.c_int64(0)
+        check(lib().scilmm_export_L(self._h, None, None, None, C.byref(nnz)), self.sym._h)
+        colptr = np.empty(self.n + 1, np.int64)
+        rowidx = np.empty(nnz.value, np.int32)
+        vals = np.empty(nnz.value, np.float64)
+        check(lib().scilmm_export_L(self._h, ptr(colptr), ptr(rowidx), ptr(vals), C.byref(nnz)), self.sym._h)
+        return sp.csc_matrix((vals, rowidx, colptr), shape=(self.n, self.n))

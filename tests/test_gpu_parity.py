@@ -1,0 +1,164 @@
+"""GPU parity: the HIP engine (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64, same permutation): logdet / solves / L / L*R relative 1e-10.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from tests.helpers import random_spd, rel_err, small_pedigree
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _engine(mats, **kw):
+    from scilmm_amd.factor import Symbolic
+    return Symbolic(mats, **kw)
+
+
+def _check_factor(mats, sigma2, sym, rs=(1, 5, 103)):
+    from oracle import oracle as O
+    V = sum(s * m for s, m in zip(sigma2, mats)).tocsr()
+    n = V.shape[0]
+    f = sym.factorize(sigma2)
+    perm = f.P()
+    assert sorted(perm.tolist()) == list(range(n))
+    o = O.OracleFactor(V, perm)
+    assert abs(f.logdet() - o.logdet()) <= TOL * max(1.0, abs(o.logdet()))
+    rng = np.random.default_rng(n)
+    for r in rs:
+        B = rng.standard_normal((n, r))
+        assert rel_err(f(B), o(B)) < TOL, ("solve", n, r)
+        assert rel_err(f.lmul(B), o.lmul(B)) < TOL, ("lmul", n, r)
+    b = rng.standard_normal(n)
+    x = f(b)
+    assert x.shape == (n,)
+    assert rel_err(V @ x, b) < 1e-9
+    Lg = f.L()
+    Lo = o.L()
+    assert rel_err((Lg @ Lg.T).toarray() if n <= 400 else (Lg @ Lg.T - Lo @ Lo.T).data.max(initial=0) + 0,
+                   (Lo @ Lo.T).toarray() if n <= 400 else 0) < 1e-9 or n > 400
+    if n <= 400:
+        assert rel_err(Lg.toarray(), Lo.toarray()) < TOL
+    return f
+
+
+@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("n,density,seed", [(1, 1.0, 0), (2, 1.0, 1), (7, 0.5, 2), (33, 0.2, 3), (64, 0.9, 4),
+                                            (65, 0.9, 5), (130, 0.5, 6), (200, 0.05, 7), (300, 0.02, 8)])
+def test_random_spd_single_matrix(n, density, seed, mfma, monkeypatch):
+    monkeypatch.setenv("SCILMM_NO_MFMA", "0" if mfma == "1" else "1")
+    A = random_spd(n, density, seed)
+    for ordering in ("amd", "natural"):
+        sym = _engine([A], ordering=ordering)
+        _check_factor([A], [1.0], sym, rs=(1, 5, 103, 130))
+
+
+def test_dense_block_chain():
+    """A fully dense SPD matrix: exercises the split-supernode chain (the dominant case at scale)."""
+    rng = np.random.default_rng(0)
+    n = 300
+    G = rng.standard_normal((n, n))
+    A = sp.csr_matrix(G @ G.T + n * np.eye(n))
+    sym = _engine([A], ordering="natural")
+    _check_factor([A], [1.0], sym)
+
+
+def test_two_components_identity():
+    A = random_spd(150, 0.1, 11)
+    I = sp.identity(150, format="csr")
+    sym = _engine([A, I])
+    for s2 in ([0.4, 0.6], [1.3, 0.01], [1e-3, 2.0]):
+        _check_factor([A, I], s2, sym, rs=(3,))
+
+
+def test_refactorize_reuses_symbolic():
+    from oracle import oracle as O
+    A = random_spd(120, 0.1, 12)
+    I = sp.identity(120, format="csr")
+    sym = _engine([A, I])
+    f = sym.factorize([0.5, 0.5])
+    ld1 = f.logdet()
+    f.refactorize([0.2, 0.9])
+    V = (0.2 * A + 0.9 * I).tocsr()
+    o = O.OracleFactor(V, f.P())
+    assert abs(f.logdet() - o.logdet()) < TOL * abs(o.logdet())
+    assert abs(ld1 - f.logdet()) > 1e-3
+
+
+def test_user_permutation_and_L_uniqueness():
+    from oracle import oracle as O
+    A = random_spd(90, 0.15, 13)
+    perm = np.random.default_rng(1).permutation(90)
+    sym = _engine([A], perm=perm)
+    f = sym.factorize([1.0])
+    assert np.array_equal(f.P(), perm)
+    d = O.DenseFactor(A, perm)
+    assert rel_err(f.L().toarray(), d.L().toarray()) < TOL
+
+
+def test_not_positive_definite_reports_column():
+    from scilmm_amd._lib import NotPositiveDefiniteError
+    A = sp.csr_matrix(np.array([[1.0, 2.0, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 1.0]]))
+    sym = _engine([A], ordering="natural")
+    with pytest.raises(NotPositiveDefiniteError) as ei:
+        sym.factorize([1.0])
+    assert ei.value.column == 1
+
+
+def test_quadforms_and_spmm():
+    from oracle import oracle as O
+    A = random_spd(257, 0.05, 14)
+    I = sp.identity(257, format="csr")
+    sym = _engine([A, I])
+    rng = np.random.default_rng(3)
+    for r in (1, 2, 100, 140):
+        U = rng.standard_normal((257, r))
+        assert rel_err(sym.quadforms(0, U), O.quadforms(A, U)) < 1e-12
+        assert rel_err(sym.quadforms(1, U), (U * U).sum(axis=0)) < 1e-12
+    X = rng.standard_normal((257, 3))
+    assert rel_err(sym.spmm(0, X), A @ X) < 1e-12
+    assert rel_err(sym.spmm(1, X), X) < 1e-12
+    x = rng.standard_normal(257)
+    assert rel_err(sym.spmm(0, x), A @ x) < 1e-12
+
+
+def test_pedigree_10k_config():
+    """BASELINE config 1 shape (10k simulated pedigree, sf 0.001), V = 0.4 A + 0.6 I."""
+    from oracle import oracle as O
+    A, _ = small_pedigree(10000, 0.001, 0)
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    sym = _engine([A, I])
+    f = sym.factorize([0.4, 0.6])
+    V = (0.4 * A + 0.6 * I).tocsr()
+    o = O.OracleFactor(V, f.P())
+    assert abs(f.logdet() - o.logdet()) < TOL * abs(o.logdet())
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 103))
+    assert rel_err(f(B), o(B)) < TOL
+    assert rel_err(f.lmul(B), o.lmul(B)) < TOL
+    s = O.SuperLUFactor(V)
+    assert abs(f.logdet() - s.logdet()) < 1e-9 * abs(s.logdet())
+    assert rel_err(f(B[:, :4]), s(B[:, :4])) < 1e-9
+    U = f(B)
+    assert rel_err(sym.quadforms(0, U), O.quadforms(A, U)) < 1e-11
+
+
+def test_pedigree_denser_10k():
+    """sf 0.01: has ~900-wide dense fronts -> multi-block chains with real descendants."""
+    from oracle import oracle as O
+    A, _ = small_pedigree(10000, 0.01, 0)
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    sym = _engine([A, I])
+    f = sym.factorize([0.4, 0.6])
+    V = (0.4 * A + 0.6 * I).tocsr()
+    o = O.OracleFactor(V, f.P())
+    assert abs(f.logdet() - o.logdet()) < TOL * abs(o.logdet())
+    rng = np.random.default_rng(6)
+    B = rng.standard_normal((n, 103))
+    assert rel_err(f(B), o(B)) < TOL
+    assert rel_err(f.lmul(B), o.lmul(B)) < TOL
