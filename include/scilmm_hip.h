@@ -53,6 +53,8 @@ typedef struct scilmm_info {
   double flops;         /* sum_j colcount_j^2 (CHOLMOD "fl" convention) */
   int64_t n_rows_total; /* sum_s m_s */
   int64_t n_updates;    /* number of (target, descendant) update pairs */
+  double update_flops;  /* algorithmic flops of the supernodal update kernel (lower-triangular count) */
+  double solve_flops_per_rhs; /* 4 nnz(L_stored) : forward + backward sweep per right-hand side */
 } scilmm_info;
 
 /* --- symbolic phase: replaces cholmod_analyze inside sk_cholesky (SparseCholesky.py:23-26), but once per
@@ -104,8 +106,14 @@ int scilmm_sync(scilmm_symbolic* sym);
 typedef struct scilmm_timing {
   double assemble_ms, factor_ms, solve_fwd_ms, solve_bwd_ms, lmul_ms, quad_ms;
   int64_t n_launches;
+  /* filled when profiling is on: HIP-event time summed per kernel class over the last factorize */
+  double update_ms, potrf_ms, trsm_ms;
+  int64_t n_update_launches;
 } scilmm_timing;
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
+/* Bracket every kernel class of the factorization with HIP events on the handle's stream (bench.py's
+ * live roofline figure).  Off by default. */
+int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on);
 
 const char* scilmm_version(void);
 

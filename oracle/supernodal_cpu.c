@@ -60,8 +60,17 @@ int sncpu_factorize(int32_t ns, const int32_t* sn_start, const int64_t* sn_rowpt
         free(W);
         W = (double*)malloc(sizeof(double) * wcap);
       }
-      /* W (mm x nn) = Ld[p0:md, :] * Ld[p0:p1, :]^T */
-      p_dgemm(&N, &T, &mm, &nn, &wd, &one, (double*)Pd + p0, &md, (double*)Pd + p0, &md, &zero, W, &mm);
+      /* W (mm x nn) = Ld[p0:md, :] * Ld[p0:p1, :]^T  (tiny products inline: BLAS call overhead dominates) */
+      if ((double)mm * nn * wd < 4096.0) {
+        for (int32_t q = 0; q < nn; ++q)
+          for (int32_t t = q; t < mm; ++t) {
+            double acc = 0.0;
+            for (int32_t k = 0; k < wd; ++k) acc += Pd[(size_t)k * md + p0 + t] * Pd[(size_t)k * md + p0 + q];
+            W[(size_t)q * mm + t] = acc;
+          }
+      } else {
+        p_dgemm(&N, &T, &mm, &nn, &wd, &one, (double*)Pd + p0, &md, (double*)Pd + p0, &md, &zero, W, &mm);
+      }
       for (int32_t q = 0; q < nn; ++q) {
         double* col = P + (size_t)(rd[p0 + q] - c0) * m;
         const double* wq = W + (size_t)q * mm;
@@ -69,14 +78,29 @@ int sncpu_factorize(int32_t ns, const int32_t* sn_start, const int64_t* sn_rowpt
       }
     }
     int info = 0;
-    p_dpotrf(&Lo, &w, P, &m, &info);
+    if ((double)m * w * w < 8192.0) {
+      /* small front: unblocked right-looking Cholesky of the whole m x w panel */
+      for (int32_t j = 0; j < w && info == 0; ++j) {
+        double d = P[(size_t)j * m + j];
+        if (!(d > 0.0)) { info = j + 1; break; }
+        d = sqrt(d);
+        P[(size_t)j * m + j] = d;
+        for (int32_t i = j + 1; i < m; ++i) P[(size_t)j * m + i] /= d;
+        for (int32_t k = j + 1; k < w; ++k) {
+          double lkj = P[(size_t)j * m + k];
+          for (int32_t i = k; i < m; ++i) P[(size_t)k * m + i] -= P[(size_t)j * m + i] * lkj;
+        }
+      }
+    } else {
+      p_dpotrf(&Lo, &w, P, &m, &info);
+      if (info == 0 && m > w) {
+        int32_t u = m - w;
+        p_dtrsm(&R, &Lo, &T, &N, &u, &w, &one, P, &m, P + w, &m);
+      }
+    }
     if (info != 0) {
       free(pos); free(W);
       return 1 + c0 + (info > 0 ? info - 1 : 0);
-    }
-    if (m > w) {
-      int32_t u = m - w;
-      p_dtrsm(&R, &Lo, &T, &N, &u, &w, &one, P, &m, P + w, &m);
     }
     /* clear the strict upper part of the diagonal block (never referenced, keeps exports clean) */
     for (int32_t j = 1; j < w; ++j)

@@ -1,0 +1,410 @@
+"""Drop-in surface of reference ``scilmm/SparseCholesky.py`` on top of the MI355X engine.
+
+Same module-level names, argument order and return values as the reference (file:line cited per
+function), so that ``from scilmm_amd import SparseCholesky, REML, HE, run_estimates`` and the
+``--A --phe --cov --reml --ignore_indices`` CLI behave like the reference's.  What differs is HOW one
+likelihood evaluation is computed when ``cholesky_func`` is the HIP ``SparseCholesky``:
+
+* the pattern of V is analysed ONCE per list of matrices (the reference re-runs CHOLMOD's analysis on
+  every evaluation, SparseCholesky.py:22-26,92) and the A_k values live in HBM;
+* V = sum s2_k A_k is assembled on the device (no scipy ``csr*scalar``/``+=``/``tocsc``, :55-59);
+* the four solves of an evaluation (:30,:32,:52,:100) become ONE multi-column sweep over
+  ``[C | y | P^T L R]`` (V^-1(y - C b) = V^-1 y - (V^-1 C) b by linearity);
+* ``factor.L().dot(R)[argsort(P)]`` (:50-51) is a supernodal product on the device (no CSC export);
+* ``sum((A_k U) * U)`` (:65), ``v' A_k v`` (:66) and ``C' V^-1 A_k V^-1 C`` (:70) come from one fused
+  SpMM+reduce per matrix (off-diagonal entries of the c x c block by polarisation).
+
+Any other callable obeying the factor protocol (``factor(b)``, ``.L()``, ``.P()``, ``.logdet()``) is
+accepted as ``cholesky_func`` exactly as in the reference and takes the reference-shaped path; there is
+no silent fallback: constructing ``SparseCholesky()`` without the built HIP library raises.
+"""
+import time
+
+import numpy as np
+import pandas as pd
+import scipy.linalg as la
+import scipy.optimize as optimize
+import scipy.sparse as sparse
+from scipy.io import mmread
+
+from . import _lib
+from .factor import Symbolic
+
+np.set_printoptions(precision=3, linewidth=200)
+pd.set_option('display.width', 200)
+
+
+def _pattern_key(mats):
+    key = []
+    for m in mats:
+        key.append((m.shape[0], m.nnz, hash(m.indptr.tobytes()), hash(m.indices.tobytes())))
+    return tuple(key)
+
+
+class SparseCholesky(object):
+    """Reference ``SparseCholesky`` (SparseCholesky.py:16-26): a callable ``V -> factor``.
+
+    ``use_long`` / ``mode`` / ``ordering_method`` are accepted for signature compatibility; the engine is
+    always supernodal with 64-bit offsets, and orders with its own approximate minimum degree
+    (``ordering_method='natural'`` or a ``perm=`` array select the other two orderings).
+    """
+
+    def __init__(self, use_long=False, mode='supernodal', ordering_method='nesdis', perm=None, fused=True):
+        _lib.lib()  # fail loudly when the HIP library is not built
+        self._use_long = use_long
+        self._mode = mode
+        self._ordering_method = ordering_method
+        self._perm = perm
+        self.fused = fused
+        self._cache = {}
+
+    def _ordering(self):
+        return 'natural' if self._ordering_method == 'natural' else 'amd'
+
+    def engine_for(self, mats):
+        """Symbolic analysis (cached per sparsity pattern) with the values of ``mats`` resident in HBM."""
+        mats = [sparse.csr_matrix(m) for m in mats]
+        for m in mats:
+            m.sort_indices()
+        key = _pattern_key(mats)
+        hit = self._cache.get(key)
+        if hit is None:
+            sym = Symbolic(mats, perm=self._perm, ordering=self._ordering())
+            self._cache = {key: (sym, [m.data.copy() for m in mats])}
+            return sym
+        sym, datas = hit
+        for k, m in enumerate(mats):
+            if not np.array_equal(datas[k], m.data):
+                sym.set_values(k, m.data)
+                datas[k] = m.data.copy()
+        return sym
+
+    def __call__(self, sparse_mat):
+        sym = self.engine_for([sparse_mat])
+        return sym.factorize([1.0])
+
+
+def _is_hip(cholesky_func):
+    return isinstance(cholesky_func, SparseCholesky)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Reference-shaped building blocks (used with any factor-protocol object)
+
+def estimate_fixed_effects(factor, y, covariates):
+    """GLS fixed effects (SparseCholesky.py:29-34)."""
+    invV_C = factor(covariates)
+    L_CT_invV_C = la.cho_factor(covariates.T.dot(invV_C))
+    fixed_effects = la.cho_solve(L_CT_invV_C, covariates.T.dot(factor(y)))
+    mu = covariates.dot(fixed_effects)
+    return invV_C, L_CT_invV_C, mu, fixed_effects
+
+
+def negative_log_likelihood(factor, y, invV_y, mu, L_CT_invV_C, reml):
+    """-log-likelihood up to constants (SparseCholesky.py:37-46)."""
+    n = y.size
+    nll = 0.5 * ((y - mu).dot(invV_y) + n * np.log(2 * np.pi) + factor.logdet())
+    if reml:
+        nll += np.sum(np.log(np.diag(L_CT_invV_C[0])))
+    return nll
+
+
+def simulate_vector(factor, n, sim_num, p_inv):
+    """U = V^-1 (P^T L R) with R ~ N(0, I) from the global legacy RNG (SparseCholesky.py:49-52)."""
+    R = np.random.randn(n, sim_num)
+    if hasattr(factor, 'lmul'):
+        return factor(factor.lmul(R))
+    return factor(factor.L().dot(R)[p_inv])
+
+
+def matrices_weighted_sum(mats, sig2g_array):
+    """V = sum_k s2_k A_k as CSC (SparseCholesky.py:55-59); only used on the reference-shaped path."""
+    V = sig2g_array[0] * mats[0]
+    for i in range(1, len(sig2g_array)):
+        V = V + sig2g_array[i] * mats[i]
+    return V.tocsc()
+
+
+def compute_gradients(sig2g_array, mats, sim_vec, invV_y, reml, invV_C, L_CT_invV_C):
+    """Monte-Carlo gradient of the negative log-likelihood (SparseCholesky.py:62-74)."""
+    grad = np.zeros(len(sig2g_array))
+    for k in range(len(sig2g_array)):
+        AU = mats[k].dot(sim_vec)
+        tr_est = np.mean(np.sum(AU * sim_vec, axis=0))
+        quad = invV_y.dot(mats[k].dot(invV_y))
+        grad[k] = 0.5 * (tr_est - quad)
+        if reml:
+            grad[k] -= 0.5 * np.trace(la.cho_solve(L_CT_invV_C, invV_C.T.dot(mats[k].dot(invV_C))))
+    return grad
+
+
+def _polar_columns(c):
+    pairs = [(a, b) for a in range(c) for b in range(a + 1, c)]
+    return pairs
+
+
+def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num):
+    """One likelihood + gradient evaluation on the device (fused form of SparseCholesky.py:88-109)."""
+    sym = cholesky_func.engine_for(mats)
+    state = cholesky_func.__dict__.setdefault('_factor_state', {})
+    fac = state.get(id(sym))
+    if fac is None:
+        state.clear()
+        fac = state[id(sym)] = sym.factorize(sig2g_array)
+    else:
+        fac.refactorize(sig2g_array)
+    n = y.size
+    c = covariates.shape[1]
+    R = np.random.randn(n, sim_num)
+    Z = fac.lmul(R)
+    if cholesky_func.fused:
+        X = fac(np.hstack([covariates, y[:, None], Z]))
+        invV_C, invV_y0, U = X[:, :c], X[:, c], X[:, c + 1:]
+        L_CT_invV_C = la.cho_factor(covariates.T.dot(invV_C))
+        beta = la.cho_solve(L_CT_invV_C, covariates.T.dot(invV_y0))
+        mu = covariates.dot(beta)
+        invV_y = invV_y0 - invV_C.dot(beta)
+    else:
+        invV_C, L_CT_invV_C, mu, beta = estimate_fixed_effects(fac, y, covariates)
+        invV_y = fac(y - mu)
+        U = fac(Z)
+    nll = negative_log_likelihood(fac, y, invV_y, mu, L_CT_invV_C, reml)
+    # gradient: one fused SpMM+reduce per matrix over [U | v | C-columns and pairwise sums]
+    cols = [U, invV_y[:, None]]
+    pairs = _polar_columns(c) if reml else []
+    if reml:
+        cols.append(invV_C)
+        for a, b in pairs:
+            cols.append((invV_C[:, a] + invV_C[:, b])[:, None])
+    Q = np.ascontiguousarray(np.hstack(cols))
+    grad = np.zeros(len(sig2g_array))
+    for k in range(len(sig2g_array)):
+        q = sym.quadforms(k, Q)
+        grad[k] = 0.5 * (np.mean(q[:sim_num]) - q[sim_num])
+        if reml:
+            M = np.zeros((c, c))
+            d = q[sim_num + 1: sim_num + 1 + c]
+            M[np.arange(c), np.arange(c)] = d
+            for t, (a, b) in enumerate(pairs):
+                M[a, b] = M[b, a] = 0.5 * (q[sim_num + 1 + c + t] - d[a] - d[b])
+            grad[k] -= 0.5 * np.trace(la.cho_solve(L_CT_invV_C, M))
+    return nll, grad, fac
+
+
+def bolt_gradient_estimation(log_sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num, verbose,
+                             take_exp=True):
+    """nll and d nll / d log(sigma2) at one point (SparseCholesky.py:77-117)."""
+    sig2g_array = np.exp(log_sig2g_array) if take_exp else np.asarray(log_sig2g_array, dtype=float)
+    if verbose:
+        t0 = time.time()
+        print('estimating nll and its gradient at:', sig2g_array)
+    if _is_hip(cholesky_func):
+        nll, grad, _ = _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num)
+    else:
+        V = matrices_weighted_sum(mats, sig2g_array)
+        n = V.shape[0]
+        factor = cholesky_func(V)
+        P_inv = np.argsort(factor.P())
+        invV_C, L_CT_invV_C, mu, _ = estimate_fixed_effects(factor, y, covariates)
+        invV_y = factor(y - mu)
+        nll = negative_log_likelihood(factor, y, invV_y, mu, L_CT_invV_C, reml)
+        sim_vec = simulate_vector(factor, n, sim_num, P_inv)
+        grad = compute_gradients(sig2g_array, mats, sim_vec, invV_y, reml, invV_C, L_CT_invV_C)
+    if take_exp:
+        grad = grad * sig2g_array
+    if verbose:
+        print("grad : ", grad)
+        print('nll: %0.8e   computation time: %0.2f seconds' % (nll, time.time() - t0))
+    return nll, grad
+
+
+def estimate_var_comps(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=True, aireml=False):
+    """HE start, then L-BFGS-B on log sigma2 (SparseCholesky.py:120-144)."""
+    he_est = HE(mats[:-1], covariates, y, compute_stderr=False)
+    x0 = np.concatenate((he_est, [1 - he_est.sum()]))
+    if np.any(x0 < 0):
+        x0 = np.ones((len(mats)))
+    x0 = x0 / x0.sum()
+    if aireml:
+        raise NotImplementedError('AI-REML is broken')
+    optObj = optimize.minimize(bolt_gradient_estimation, np.log(x0),
+                               args=(cholesky_func, mats, covariates, y, reml, sim_num, verbose, True),
+                               jac=True, method='L-BFGS-B', options={'eps': 1e-5, 'ftol': 1e-7})
+    if not optObj.success:
+        print('optimization failed with message: %s' % optObj.message)
+    return np.exp(optObj.x)
+
+
+def _final_factor(cholesky_func, mats, coefficients):
+    if _is_hip(cholesky_func):
+        return cholesky_func.engine_for(mats).factorize(coefficients)
+    return cholesky_func(matrices_weighted_sum(mats, coefficients))
+
+
+def compute_hess(mats, covariates, factor, y):
+    """AI-style Hessian of the log-likelihood by projected solves (SparseCholesky.py:147-168)."""
+    K = len(mats)
+    Vinv_C = factor(covariates)
+    L_CT_Vinv_C = la.cho_factor(covariates.T.dot(Vinv_C))
+
+    def project(z):
+        Vinv_z = factor(z)
+        return Vinv_z - Vinv_C.dot(la.cho_solve(L_CT_Vinv_C, covariates.T.dot(Vinv_z)))
+
+    Py = project(y)
+    hess = np.empty((K, K))
+    for j in range(K):
+        P_Hj_Py = project(mats[j].dot(Py))
+        for i in range(j + 1):
+            hess[i, j] = hess[j, i] = -0.5 * y.dot(project(mats[i].dot(P_Hj_Py)))
+    return hess
+
+
+def compute_varcomp_stderr(mats, covariates, factor, y, sim_num):
+    """sqrt(diag((-H)^-1) (1 + 1/s)) (SparseCholesky.py:171-174)."""
+    hess = compute_hess(mats, covariates, factor, y)
+    return np.sqrt(np.diag(la.inv(-hess)) * (1 + 1.0 / sim_num))
+
+
+def REML(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=False):
+    """REML fit (SparseCholesky.py:177-189). Returns the reference's dict of three arrays."""
+    y = y / y.std()
+    mats = list(mats) + [sparse.eye(y.shape[0]).tocsr()]
+    varcomp_estimates = estimate_var_comps(cholesky_func, mats, covariates, y, reml, sim_num, verbose)
+    factor = _final_factor(cholesky_func, mats, varcomp_estimates)
+    _, _, _, fixed_effects = estimate_fixed_effects(factor, y, covariates)
+    sigmas_sigmas = compute_varcomp_stderr(mats, covariates, factor, y, sim_num)
+    return {"covariance coefficients": varcomp_estimates,
+            "covariates coefficients": fixed_effects,
+            "covariance std": sigmas_sigmas}
+
+
+def HE(mat_list, cov, y, MQS=False, verbose=False, sim_num=100, compute_stderr=False, y2=None):
+    """Haseman-Elston moment estimator (SparseCholesky.py:192-281); REML's starting point (:121).
+
+    The Monte-Carlo standard error follows the evident intent of the reference loop (:259-278), whose
+    inner variable shadowing (``mat_i``/``mat_j``) makes it raise for more than one matrix.
+    """
+    mat_list = list(mat_list)
+    CTC = cov.T.dot(cov)
+    y = y - cov.dot(np.linalg.solve(CTC, cov.T.dot(y)))
+    y = y / y.std()
+    if y2 is not None:
+        y2 = y2 - cov.dot(np.linalg.solve(CTC, cov.T.dot(y2)))
+        y2 = y2 / y2.std()
+        y = np.concatenate((y, y2))
+        for m_i, m in enumerate(mat_list):
+            z = sparse.csr_matrix((m.shape[0], m.shape[0]))
+            mat_list[m_i] = sparse.vstack([sparse.hstack([z, m]), sparse.hstack([m, z])]).tocsr()
+    K = len(mat_list)
+    n = y.shape[0]
+    q = np.zeros(K)
+    S = np.zeros((K, K))
+    for i, mat_i in enumerate(mat_list):
+        if MQS:
+            q[i] = y.dot(mat_i.dot(y)) - y.dot(y)
+        elif sparse.issparse(mat_i):
+            q[i] = y.dot(mat_i.dot(y)) - mat_i.diagonal().dot(y ** 2)
+        else:
+            q[i] = y.dot(mat_i.dot(y)) - np.diag(mat_i).dot(y ** 2)
+        for j in range(i + 1):
+            mat_j = mat_list[j]
+            if MQS:
+                S[i, j] = (mat_i.multiply(mat_j)).sum() - (n - 1)
+            elif sparse.issparse(mat_i):
+                S[i, j] = (mat_i.multiply(mat_j)).sum() - mat_i.diagonal().dot(mat_j.diagonal())
+            else:
+                S[i, j] = np.einsum('ij,ij->', mat_i, mat_j) - np.diag(mat_i).dot(np.diag(mat_j))
+            S[j, i] = S[i, j]
+    he_est = np.linalg.solve(S, q)
+    if not compute_stderr:
+        return he_est
+    H = mat_list[0] * he_est[0]
+    for mat_k, sigma2_k in zip(mat_list[1:], he_est[1:]):
+        H = H + mat_k * sigma2_k
+    H = H + sparse.eye(n, format='csr') * (1.0 - he_est.sum())
+    V_q = np.empty((K, K))
+    for i, mat_i in enumerate(mat_list):
+        for j, mat_j in enumerate(mat_list[:i + 1]):
+            if sim_num is None:
+                HAi = H.dot(mat_i) - H
+                HAj = H.dot(mat_j) - H
+                V_q[i, j] = 2 * (HAi.multiply(HAj)).sum()
+            else:
+                sim_y = np.random.randn(n, sim_num)
+                t = mat_j.dot(sim_y) - sim_y
+                t = H.dot(t)
+                t = mat_i.dot(t) - t
+                t = H.dot(t)
+                V_q[i, j] = 2 * np.mean(np.einsum('ij,ij->j', sim_y, t))
+            V_q[j, i] = V_q[i, j]
+    var_he_est = np.linalg.solve(S, np.linalg.solve(S, V_q).T).T
+    return he_est, np.sqrt(np.diag(var_he_est))
+
+
+def run_estimates(A, df_phe, df_cov, reml=False, ignore_indices=False, df_phe2=None):
+    """Align inputs, drop unrelated individuals, standardise covariates, fit (SparseCholesky.py:350-395)."""
+    A = sparse.csr_matrix(A)
+    if not ignore_indices:
+        indices = sorted(set(df_cov.index) & set(df_phe.index) & set(A.indices))
+        df_cov = df_cov.loc[indices]
+        df_phe = df_phe.loc[indices]
+        if df_phe2 is not None:
+            df_phe2 = df_phe2.loc[indices]
+        A = A[indices][:, indices]
+    has_relatives = np.asarray(A.sum(axis=1))[:, 0] > 1
+    if any(~has_relatives):
+        A = A[has_relatives][:, has_relatives]
+        df_cov = df_cov.loc[has_relatives]
+        df_phe = df_phe.loc[has_relatives]
+        if df_phe2 is not None:
+            df_phe2 = df_phe2.loc[has_relatives]
+    A.eliminate_zeros()
+    y = np.asarray(df_phe.values, dtype=float).reshape(-1)
+    y2 = None
+    if df_phe2 is not None:
+        y2 = np.asarray(df_phe2.values, dtype=float).reshape(-1)
+        assert not reml
+    if isinstance(df_cov, pd.Series):
+        df_cov = df_cov.to_frame()
+    df_cov = df_cov.copy()
+    df_cov['intercept'] = 1
+    cov = df_cov.values.copy().astype(float)
+    cov[:, :-1] -= cov[:, :-1].mean(axis=0)
+    cov[:, :-1] /= cov[:, :-1].std(axis=0)
+    if reml:
+        reml_d = REML(SparseCholesky(), [A], cov, y, verbose=True)
+        print("reml d are %s and %s" % (reml_d["covariance coefficients"], reml_d["covariates coefficients"]))
+        return reml_d
+    he_est = HE([A], cov, y, compute_stderr=True, y2=y2)
+    print("HE estimates are %s and %s" % (he_est[0], he_est[1]))
+    return he_est
+
+
+def run_estimates_from_paths(A, phe, cov, reml=False, ignore_indices=False):
+    """File front end (SparseCholesky.py:398-403): MatrixMarket A, header-less phenotype CSV, covariate CSV."""
+    A = mmread(A).tocsr()
+    index_col = None if ignore_indices else 0
+    df_cov = pd.read_csv(cov, index_col=index_col)
+    df_phe = pd.read_csv(phe, header=None, index_col=index_col)
+    return run_estimates(A, df_phe, df_cov, reml=reml, ignore_indices=ignore_indices)
+
+
+def _main(argv=None):
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--A', required=True, help="Path of the covariance matrix A (MatrixMarket).")
+    parser.add_argument('--phe', required=True,
+                        help="Phenotype CSV without header: IID,phenotype (only the phenotype with --ignore_indices).")
+    parser.add_argument('--cov', required=True,
+                        help="Covariates CSV with header; first column IID unless --ignore_indices.")
+    parser.add_argument('--reml', default=False, action='store_true',
+                        help="Compute using REML, default case uses the HE estimation method.")
+    parser.add_argument('--ignore_indices', default=False, action='store_true',
+                        help="Assume A, phenotypes and covariates are already in the same order.")
+    args = parser.parse_args(argv)
+    return run_estimates_from_paths(**(args.__dict__))
+
+
+if __name__ == '__main__':
+    _main()

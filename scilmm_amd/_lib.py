@@ -42,13 +42,15 @@ class Options(C.Structure):
 class Info(C.Structure):
     _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("nsuper", C.c_int32), ("nlevels", C.c_int32),
                 ("nnzL", C.c_int64), ("nnzL_stored", C.c_int64), ("nnz_pattern", C.c_int64),
-                ("flops", C.c_double), ("n_rows_total", C.c_int64), ("n_updates", C.c_int64)]
+                ("flops", C.c_double), ("n_rows_total", C.c_int64), ("n_updates", C.c_int64),
+                ("update_flops", C.c_double), ("solve_flops_per_rhs", C.c_double)]
 
 
 class Timing(C.Structure):
     _fields_ = [("assemble_ms", C.c_double), ("factor_ms", C.c_double), ("solve_fwd_ms", C.c_double),
                 ("solve_bwd_ms", C.c_double), ("lmul_ms", C.c_double), ("quad_ms", C.c_double),
-                ("n_launches", C.c_int64)]
+                ("n_launches", C.c_int64), ("update_ms", C.c_double), ("potrf_ms", C.c_double),
+                ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64)]
 
 
 # every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)
@@ -57,7 +59,7 @@ SYMBOLS = [
     "scilmm_symbolic_free", "scilmm_values_upload", "scilmm_factorize", "scilmm_refactorize",
     "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
     "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
-    "scilmm_sync", "scilmm_last_timing", "scilmm_version",
+    "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
 ]
 
 _lib = None
@@ -97,6 +99,7 @@ def lib():
     L.scilmm_quadforms_dev.argtypes = [vp, i32, vp, i32, vp]
     L.scilmm_sync.argtypes = [vp]
     L.scilmm_last_timing.argtypes = [vp, P(Timing)]
+    L.scilmm_set_profiling.argtypes = [vp, i32]
     L.scilmm_version.restype = C.c_char_p
     _lib = L
     return L

@@ -49,6 +49,8 @@ int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
   info->flops = S.flops;
   info->n_rows_total = (int64_t)S.sn_rows.size();
   info->n_updates = (int64_t)S.upd_src.size();
+  info->update_flops = S.update_flops;
+  info->solve_flops_per_rhs = 4.0 * (double)S.nnzL_stored;
   return SCILMM_OK;
 }
 

@@ -41,6 +41,9 @@ struct Dev {
   hipEvent_t ev[8];
   scilmm_timing timing{};
   bool attrs_set = false;
+  bool profiling = false;
+  int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
+  std::vector<hipEvent_t> pev;     // 4 events per level when profiling
 };
 
 #define HIPCHK(call)                                                                                   \
@@ -75,6 +78,8 @@ void dev_free(void* p) {
   if (D->partial) (void)hipFree(D->partial);
   if (D->d_out) (void)hipFree(D->d_out);
   for (auto& e : D->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : D->pev)
     if (e) (void)hipEventDestroy(e);
   if (D->stream) (void)hipStreamDestroy(D->stream);
   delete D;
@@ -224,9 +229,16 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     launches++;
   }
   HIPCHK(hipEventRecord(D->ev[1], st));
+  const bool prof = D->profiling;
+  if (prof && D->pev.size() < (size_t)4 * S.nlevels) {
+    size_t old = D->pev.size();
+    D->pev.resize((size_t)4 * S.nlevels, nullptr);
+    for (size_t i = old; i < D->pev.size(); ++i) HIPCHK(hipEventCreate(&D->pev[i]));
+  }
   for (int32_t l = 0; l < S.nlevels; ++l) {
     const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
     const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
+    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 0], st));
     if (l > 0 && t1 > t0) {
       if (D->use_mfma)
         hipLaunchKernelGGL(k_update<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L);
@@ -234,11 +246,13 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
         hipLaunchKernelGGL(k_update<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L);
       launches++;
     }
+    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 1], st));
     if (f1 > f0) {
       hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
                          fac->invD, fac->logd, fac->status);
       launches++;
     }
+    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 2], st));
     if (t1 > t0) {
       if (D->use_mfma)
         hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
@@ -248,6 +262,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
                            fac->invD);
       launches++;
     }
+    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 3], st));
   }
   HIPCHK(hipEventRecord(D->ev[2], st));
   HIPCHK(hipGetLastError());
@@ -260,6 +275,23 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   D->timing.assemble_ms = a;
   D->timing.factor_ms = f;
   D->timing.n_launches = launches;
+  if (prof) {
+    double tu = 0, tp = 0, tt = 0;
+    int64_t nu = 0;
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+      float x = 0;
+      HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 0], D->pev[4 * l + 1]));
+      if (l > 0 && S.level_tile_ptr[l + 1] > S.level_tile_ptr[l]) { tu += x; nu++; }
+      HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 1], D->pev[4 * l + 2]));
+      tp += x;
+      HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 2], D->pev[4 * l + 3]));
+      tt += x;
+    }
+    D->timing.update_ms = tu;
+    D->timing.potrf_ms = tp;
+    D->timing.trsm_ms = tt;
+    D->timing.n_update_launches = nu;
+  }
   if (status != 0x7fffffff) {
     if (bad_col) *bad_col = status;
     return SCILMM_ERR_NOT_PD;
@@ -347,10 +379,12 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
   if (!mid_recorded) HIPCHK(hipEventRecord(D->ev[4], st));
   HIPCHK(hipEventRecord(D->ev[5], st));
   HIPCHK(hipGetLastError());
+  D->rhs_pending = mode;
   return SCILMM_OK;
 }
 
 int finish_rhs_timing(scilmm_symbolic* sym, Dev* D, int mode) {
+  D->rhs_pending = -1;
   float a = 0, b = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[3], D->ev[4]));
   HIPCHK(hipEventElapsedTime(&b, D->ev[4], D->ev[5]));
@@ -610,12 +644,22 @@ int scilmm_sync(scilmm_symbolic* sym) {
   if (!sym || !sym->device) return SCILMM_ERR_ARG;
   Dev* D = (Dev*)sym->device;
   HIPCHK(hipStreamSynchronize(D->stream));
+  if (D->rhs_pending >= 0) return finish_rhs_timing(sym, D, D->rhs_pending);
   return SCILMM_OK;
 }
 
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out) {
   if (!sym || !sym->device || !out) return SCILMM_ERR_ARG;
   *out = ((Dev*)sym->device)->timing;
+  return SCILMM_OK;
+}
+
+int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on) {
+  if (!sym || !sym->S) return SCILMM_ERR_ARG;
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  D->profiling = on != 0;
   return SCILMM_OK;
 }
 

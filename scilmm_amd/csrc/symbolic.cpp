@@ -12,6 +12,9 @@
 #include <cassert>
 #include <cstring>
 #include <numeric>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace scilmm {
 
@@ -131,6 +134,13 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   Symbolic* S = new Symbolic();
   S->n = n;
   S->K = K;
+  const bool verbose = getenv("SCILMM_VERBOSE") != nullptr;
+  auto tlast = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    auto now = std::chrono::steady_clock::now();
+    if (verbose) fprintf(stderr, "[scilmm symbolic] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - tlast).count());
+    tlast = now;
+  };
   // ---------------------------------------------------------------- 1. union lower pattern (original labels, by row)
   S->is_diag.assign(K, 1);
   std::vector<int64_t> uptr(n + 1, 0);
@@ -176,6 +186,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   }
   S->nnz_pattern = uptr[n];
 
+  lap("union pattern");
   // ---------------------------------------------------------------- 2. ordering
   std::vector<int32_t> perm(n);
   if (opts.ordering == 2) {
@@ -214,6 +225,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   std::vector<int32_t> iperm(n);
   for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
 
+  lap("ordering");
   // ---------------------------------------------------------------- 3. permuted strict-lower pattern by column
   auto build_csc = [&](const std::vector<int32_t>& ip, std::vector<int64_t>& cptr, std::vector<int32_t>& cidx) {
     cptr.assign(n + 1, 0);
@@ -242,6 +254,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   build_csc(iperm, cptr, cidx);
   transpose_pattern(n, cptr, cidx, rptr, ridx);
 
+  lap("permute pattern");
   // ---------------------------------------------------------------- 4. etree + postorder, relabel
   std::vector<int32_t> parent;
   etree(n, rptr, ridx, parent);
@@ -268,6 +281,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   S->iperm = iperm;
   S->parent = parent;
 
+  lap("etree+postorder+relabel");
   // ---------------------------------------------------------------- 5. column counts
   std::vector<int32_t> cc;
   column_counts(n, parent, post, cptr, cidx, cc);
@@ -279,6 +293,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     S->flops += (double)cc[j] * (double)cc[j];
   }
 
+  lap("column counts");
   // ---------------------------------------------------------------- 6. supernodes (fundamental, then relaxed)
   struct SN { int32_t start, end, m; int64_t zeros; };
   std::vector<SN> out;
@@ -340,6 +355,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   for (int32_t s = 0; s < ns; ++s)
     for (int32_t j = out[s].start; j < out[s].end; ++j) snode_of[j] = s;
 
+  lap("supernodes");
   // ---------------------------------------------------------------- 7. row structure of every supernode
   S->sn_rowptr.assign(ns + 1, 0);
   S->sn_parent.assign(ns, -1);
@@ -379,6 +395,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       }
     }
   }
+  lap("row structures");
   // ---------------------------------------------------------------- 8. panel offsets, levels
   S->sn_loff.assign(ns + 1, 0);
   for (int32_t s = 0; s < ns; ++s) {
@@ -409,6 +426,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       if (S->sn_parent[s] != -1) S->child_idx[fill[S->sn_parent[s]]++] = s;
   }
 
+  lap("offsets/levels/children");
   // ---------------------------------------------------------------- 9. value-assembly maps
   // pattern slots are numbered in permuted CSC order with the diagonal first in each column.
   {
@@ -454,44 +472,63 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
           }
         continue;
       }
-      int64_t cntk = 0;
+      // bucket the stored lower entries of matrix k by permuted column, sort each bucket by permuted
+      // row and merge it against the (sorted) pattern column: cache-friendly, O(nnz log colsize).
+      std::vector<int64_t> bptr(n + 1, 0);
       for (int32_t i = 0; i < n; ++i)
-        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
-          if (indices[k][e] <= i && indices[k][e] >= 0) cntk++;
-      S->val_slot[k].resize(cntk);
-      S->val_src[k].resize(cntk);
-      std::vector<int64_t> rowoff(n + 1, 0);
-      for (int32_t i = 0; i < n; ++i) {
-        int64_t c = 0;
-        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
-          if (indices[k][e] <= i && indices[k][e] >= 0) c++;
-        rowoff[i + 1] = rowoff[i] + c;
-      }
-#pragma omp parallel for schedule(dynamic, 1024)
-      for (int32_t i = 0; i < n; ++i) {
-        int64_t o = rowoff[i];
         for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
           int32_t j = indices[k][e];
           if (j > i || j < 0) continue;
-          int32_t a = iperm[i], b = iperm[j];
-          int32_t col = std::min(a, b), row = std::max(a, b);
-          int64_t sl;
-          if (row == col) {
-            sl = slot_ptr[col];
-          } else {
-            const int32_t* lo = cidx.data() + cptr[col];
-            const int32_t* hi = cidx.data() + cptr[col + 1];
-            const int32_t* it = std::lower_bound(lo, hi, row);
-            sl = slot_ptr[col] + 1 + (it - lo);
+          bptr[std::min(iperm[i], iperm[j]) + 1]++;
+        }
+      for (int32_t c = 0; c < n; ++c) bptr[c + 1] += bptr[c];
+      const int64_t cntk = bptr[n];
+      std::vector<int32_t> brow(cntk);
+      std::vector<int64_t> bsrc(cntk);
+      {
+        std::vector<int64_t> fill(bptr.begin(), bptr.end() - 1);
+        for (int32_t i = 0; i < n; ++i)
+          for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+            int32_t j = indices[k][e];
+            if (j > i || j < 0) continue;
+            int32_t a = iperm[i], b = iperm[j];
+            int64_t f = fill[std::min(a, b)]++;
+            brow[f] = std::max(a, b);
+            bsrc[f] = e;
           }
-          S->val_slot[k][o] = sl;
-          S->val_src[k][o] = e;
-          ++o;
+      }
+      S->val_slot[k].resize(cntk);
+      S->val_src[k].resize(cntk);
+#pragma omp parallel
+      {
+        std::vector<std::pair<int32_t, int64_t>> tmp;
+#pragma omp for schedule(dynamic, 256)
+        for (int32_t c = 0; c < n; ++c) {
+          int64_t b0 = bptr[c], b1 = bptr[c + 1];
+          tmp.resize(b1 - b0);
+          for (int64_t t = b0; t < b1; ++t) tmp[t - b0] = {brow[t], bsrc[t]};
+          std::sort(tmp.begin(), tmp.end());
+          const int32_t* lo = cidx.data() + cptr[c];
+          const int32_t* hi = cidx.data() + cptr[c + 1];
+          const int32_t* it = lo;
+          for (int64_t t = b0; t < b1; ++t) {
+            int32_t row = tmp[t - b0].first;
+            int64_t sl;
+            if (row == c) {
+              sl = slot_ptr[c];
+            } else {
+              while (it != hi && *it < row) ++it;
+              sl = slot_ptr[c] + 1 + (it - lo);
+            }
+            S->val_slot[k][t] = sl;
+            S->val_src[k][t] = tmp[t - b0].second;
+          }
         }
       }
     }
     S->nnz_pattern = slot_ptr[n];
   }
+  lap("assembly maps");
   // ---------------------------------------------------------------- 10. left-looking update schedule
   {
     S->upd_ptr.assign(ns + 1, 0);
@@ -522,6 +559,10 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         S->upd_src[f] = d;
         S->upd_p0[f] = (int32_t)(t - rb);
         S->upd_p1[f] = (int32_t)(t2 - rb);
+        {
+          const double nq = (double)(t2 - t), below = (double)(re - t2);
+          S->update_flops += (double)w * (nq * (nq + 1.0) + 2.0 * nq * below);
+        }
         t = t2;
       }
     }
@@ -535,6 +576,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     std::vector<int32_t> fill(S->level_ptr.begin(), S->level_ptr.end() - 1);
     for (int32_t s = 0; s < ns; ++s) S->level_fronts[fill[S->sn_level[s]]++] = s;
   }
+  lap("update schedule");
   // ---------------------------------------------------------------- 11. target tiles and their combos
   {
     const int32_t TM = opts.tile_rows;
@@ -592,6 +634,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         }
       }
     }
+    lap("tile combos");
     // per-level tile lists, heaviest (most combos) first for load balance
     S->level_tile_ptr.assign(S->nlevels + 1, 0);
     for (int64_t g = 0; g < nt; ++g) S->level_tile_ptr[S->sn_level[S->tile_front[g]] + 1]++;

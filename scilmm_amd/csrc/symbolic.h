@@ -80,6 +80,7 @@ struct Symbolic {
   int64_t nnzL = 0;        // true nonzeros of L (sum colcount)
   int64_t nnzL_stored = 0; // doubles of panel storage (includes relaxation zeros and the upper part of diagonal blocks)
   double flops = 0;        // sum colcount^2
+  double update_flops = 0; // algorithmic flops of all supernodal updates (lower-triangular count)
   std::string error;
 };
 

@@ -105,6 +105,15 @@ class Symbolic(object):
         check(lib().scilmm_spmm(self._h, k, ptr(X2), X2.shape[1], ptr(Y)), self._h)
         return Y.reshape(X.shape)
 
+    def set_profiling(self, on=True):
+        check(lib().scilmm_set_profiling(self._h, int(bool(on))), self._h)
+
+    def sync(self):
+        check(lib().scilmm_sync(self._h), self._h)
+
+    def quadforms_dev(self, k, dU_ptr, r, dout_ptr):
+        check(lib().scilmm_quadforms_dev(self._h, k, dU_ptr, r, dout_ptr), self._h)
+
     def timing(self):
         t = _lib.Timing()
         check(lib().scilmm_last_timing(self._h, C.byref(t)), self._h)
@@ -154,6 +163,13 @@ class Factor(object):
     def lmul(self, R):
         """(factor.L() @ R)[argsort(factor.P())] without exporting L (simulate_vector, SparseCholesky.py:50-51)."""
         return self._rhs(lib().scilmm_lmul, R)
+
+    def solve_dev(self, dB_ptr, r, dX_ptr):
+        """Device-pointer solve (row-major n x r, original row order); enqueues without synchronising."""
+        check(lib().scilmm_solve_dev(self._h, dB_ptr, r, dX_ptr), self.sym._h)
+
+    def lmul_dev(self, dR_ptr, r, dZ_ptr):
+        check(lib().scilmm_lmul_dev(self._h, dR_ptr, r, dZ_ptr), self.sym._h)
 
     def logdet(self):
         out = C.c_double(0.0)
