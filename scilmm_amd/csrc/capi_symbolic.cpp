@@ -88,6 +88,8 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
   GET("combo_pair", combo_pair)
   GET("combo_ta", combo_ta)
   GET("combo_tb", combo_tb)
+  GET("combo_ip0", combo_ip0)
+  GET("upd_jp0", upd_jp0)
   GET("level_tile_ptr", level_tile_ptr)
   GET("level_tiles", level_tiles)
   GET("level_pair_ptr", level_pair_ptr)

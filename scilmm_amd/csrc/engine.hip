@@ -41,6 +41,13 @@ struct Dev {
   hipEvent_t ev[8];
   scilmm_timing timing{};
   bool attrs_set = false;
+  // update-kernel plan: flattened combo descriptors, per-level work items (split-K), partial slots
+  ComboDesc* d_combos = nullptr;
+  UpdWork* d_work = nullptr;
+  std::vector<int64_t> work_ptr;   // [nlevels+1]
+  int32_t* d_tile_pslot = nullptr;
+  int32_t* d_tile_pnseg = nullptr;
+  double* scratch = nullptr;       // max slots per level * TM*NB doubles
   bool profiling = false;
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   std::vector<hipEvent_t> pev;     // 4 events per level when profiling
@@ -139,6 +146,99 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   D->vals.assign(S.K, nullptr);
   D->have_vals.assign(S.K, 0);
   HIPCHK(hipMalloc((void**)&D->d_out, sizeof(double) * RPMAX));
+  // ---- update-kernel plan
+  {
+    const int64_t nc = (int64_t)S.combo_pair.size();
+    std::vector<ComboDesc> cd((size_t)std::max<int64_t>(nc, 1));
+    for (int64_t c = 0; c < nc; ++c) {
+      const int32_t e = S.combo_pair[c];
+      const int32_t d = S.upd_src[e];
+      ComboDesc& x = cd[c];
+      x.loff = S.sn_loff[d];
+      x.rowoff = S.sn_rowptr[d];
+      x.md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+      x.wd = S.sn_start[d + 1] - S.sn_start[d];
+      x.ta = S.combo_ta[c];
+      x.nt = S.combo_tb[c] - S.combo_ta[c];
+      x.p0 = S.upd_p0[e];
+      x.nq = S.upd_p1[e] - S.upd_p0[e];
+      x.ip0 = S.combo_ip0[c];
+      x.jp0 = S.upd_jp0[e];
+    }
+    const ComboDesc* dc;
+    if ((st = upload(sym, D, cd, &dc)) != SCILMM_OK) return st;
+    D->d_combos = (ComboDesc*)dc;
+    const int64_t ntiles = (int64_t)S.tile_front.size();
+    std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
+    std::vector<UpdWork> work;
+    D->work_ptr.assign(S.nlevels + 1, 0);
+    int64_t max_slots = 0;
+    const char* ens = getenv("SCILMM_NO_SPLITK");
+    const bool allow_split = !(ens && ens[0] == '1');
+    // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Every level is cut
+    // into work items of about total_cost / (4 workgroups per CU) so that one launch fills the chip once
+    // with balanced items (the late levels of a dense chain have few tiles but long combo lists).
+    auto combo_cost = [&](int64_t c) -> int64_t { return 1 + (cd[c].wd + KC - 1) / KC; };
+    const int64_t target_items = 1024;
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+      int64_t total = 0;
+      for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
+        const int32_t g = S.level_tiles[i];
+        for (int64_t c = S.combo_ptr[g]; c < S.combo_ptr[g + 1]; ++c) total += combo_cost(c);
+      }
+      const int64_t min_item = 24;  // below this the fixed cost of an item (LDS clear, 64 KB partial) dominates
+      const int64_t per_item = allow_split ? std::max<int64_t>(min_item, (total + target_items - 1) / target_items)
+                                           : (int64_t)1 << 60;
+      int64_t slots = 0;
+      for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
+        const int32_t g = S.level_tiles[i];
+        const int64_t cb = S.combo_ptr[g], ce = S.combo_ptr[g + 1];
+        if (ce == cb) continue;
+        int64_t tcost = 0;
+        for (int64_t c = cb; c < ce; ++c) tcost += combo_cost(c);
+        int64_t nseg = std::min<int64_t>(64, std::max<int64_t>(1, (tcost + per_item / 2) / per_item));
+        if (nseg == 1) {
+          work.push_back(UpdWork{g, -1, cb, ce});
+          continue;
+        }
+        const int64_t seg_cost = (tcost + nseg - 1) / nseg;
+        const size_t first = work.size();
+        int64_t a = cb, acc = 0;
+        for (int64_t c = cb; c < ce; ++c) {
+          acc += combo_cost(c);
+          if (acc >= seg_cost && c + 1 < ce) {
+            work.push_back(UpdWork{g, 0, a, c + 1});
+            a = c + 1;
+            acc = 0;
+          }
+        }
+        work.push_back(UpdWork{g, 0, a, ce});
+        const int64_t made = (int64_t)(work.size() - first);
+        if (made == 1) {
+          work[first].slot = -1;
+        } else {
+          pslot[g] = (int32_t)slots;
+          pnseg[g] = (int32_t)made;
+          for (int64_t k = 0; k < made; ++k) work[first + k].slot = (int32_t)(slots + k);
+          slots += made;
+        }
+      }
+      max_slots = std::max(max_slots, slots);
+      D->work_ptr[l + 1] = (int64_t)work.size();
+    }
+    if (work.empty()) work.push_back(UpdWork{0, -1, 0, 0});
+    const UpdWork* dw;
+    if ((st = upload(sym, D, work, &dw)) != SCILMM_OK) return st;
+    D->d_work = (UpdWork*)dw;
+    if ((st = upload(sym, D, pslot, &tmp)) != SCILMM_OK) return st;
+    D->d_tile_pslot = (int32_t*)tmp;
+    if ((st = upload(sym, D, pnseg, &tmp)) != SCILMM_OK) return st;
+    D->d_tile_pnseg = (int32_t*)tmp;
+    void* sc = nullptr;
+    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)std::max<int64_t>(max_slots, 1) * TM * NB));
+    D->allocs.push_back(sc);
+    D->scratch = (double*)sc;
+  }
   *out = D;
   return SCILMM_OK;
 }
@@ -154,6 +254,8 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
   return SCILMM_OK;
 }
@@ -202,6 +304,11 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
       return SCILMM_ERR_STATE;
     }
   fac->valid = false;
+  {
+    int stc = set_attrs(sym, D);
+    if (stc != SCILMM_OK) return stc;
+  }
+  const size_t sm_upd = sizeof(double) * (size_t)(2 * KC * LDA + 2 * KC * LDB) + sizeof(int32_t) * TM;
   hipStream_t st = D->stream;
   int64_t launches = 0;
   HIPCHK(hipEventRecord(D->ev[0], st));
@@ -239,27 +346,30 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
     const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 0], st));
-    if (l > 0 && t1 > t0) {
+    const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
+    if (w1 > w0) {
       if (D->use_mfma)
-        hipLaunchKernelGGL(k_update<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L);
+        hipLaunchKernelGGL(k_update<true>, dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
+                           fac->L, D->scratch);
       else
-        hipLaunchKernelGGL(k_update<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L);
+        hipLaunchKernelGGL(k_update<false>, dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
+                           fac->L, D->scratch);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 1], st));
     if (f1 > f0) {
       hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
-                         fac->invD, fac->logd, fac->status);
+                         fac->invD, fac->logd, fac->status, D->d_tile_pslot, D->d_tile_pnseg, D->scratch);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 2], st));
     if (t1 > t0) {
       if (D->use_mfma)
         hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
-                           fac->invD);
+                           fac->invD, D->d_tile_pslot, D->d_tile_pnseg, D->scratch);
       else
         hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
-                           fac->invD);
+                           fac->invD, D->d_tile_pslot, D->d_tile_pnseg, D->scratch);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 3], st));
@@ -281,7 +391,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     for (int32_t l = 0; l < S.nlevels; ++l) {
       float x = 0;
       HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 0], D->pev[4 * l + 1]));
-      if (l > 0 && S.level_tile_ptr[l + 1] > S.level_tile_ptr[l]) { tu += x; nu++; }
+      if (D->work_ptr[l + 1] > D->work_ptr[l]) { tu += x; nu++; }
       HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 1], D->pev[4 * l + 2]));
       tp += x;
       HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 2], D->pev[4 * l + 3]));

@@ -20,7 +20,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int NB = 64;        // max supernode block width (symbolic max_width must be <= NB)
 constexpr int TM = 128;       // target rows per tile
-constexpr int KC = 32;        // k-chunk staged through LDS
+constexpr int KC = 16;        // k-chunk staged through LDS (update kernel: 2 x 28 KB -> two workgroups per CU)
 constexpr int LDA = TM + 16;  // k-major LDS leading dims: (ld*8 B) == 128 mod 256 -> conflict-free b64 reads
 constexpr int LDB = NB + 16;
 constexpr int RPMAX = 128;    // max padded RHS columns per pass
@@ -91,16 +91,33 @@ __device__ __forceinline__ void tile_mma(const double* __restrict__ As, const do
                                          int lane, int wv, d4 (&acc)[4][2]) {
   if (MFMA) {
     const int li = lane & 15, lk = lane >> 4;
-    for (int k4 = 0; k4 < kc4; k4 += 4) {
-      const int kk = k4 + lk;
-      const double b0 = As[kk * LDA + 32 * wv + li];
-      const double b1 = As[kk * LDA + 32 * wv + 16 + li];
+    const double* ap = As + lk * LDA + 32 * wv + li;
+    const double* bp = Bs + lk * LDB + li;
+    if (ncb == 4) {
+      // full-width target block: straight-line body, all six LDS reads issued ahead of the eight MFMAs
+#pragma unroll 2
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        const double b0 = ap[k4 * LDA], b1 = ap[k4 * LDA + 16];
+        const double a0 = bp[k4 * LDB], a1 = bp[k4 * LDB + 16], a2 = bp[k4 * LDB + 32], a3 = bp[k4 * LDB + 48];
+        acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+        acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+        acc[2][0] = mfma_f64(a2, b0, acc[2][0]);
+        acc[2][1] = mfma_f64(a2, b1, acc[2][1]);
+        acc[3][0] = mfma_f64(a3, b0, acc[3][0]);
+        acc[3][1] = mfma_f64(a3, b1, acc[3][1]);
+      }
+    } else {
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        const double b0 = ap[k4 * LDA], b1 = ap[k4 * LDA + 16];
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        if (jb < ncb) {
-          const double a = Bs[kk * LDB + 16 * jb + li];
-          acc[jb][0] = mfma_f64(a, b0, acc[jb][0]);
-          acc[jb][1] = mfma_f64(a, b1, acc[jb][1]);
+        for (int jb = 0; jb < 4; ++jb) {
+          if (jb < ncb) {
+            const double a = bp[k4 * LDB + 16 * jb];
+            acc[jb][0] = mfma_f64(a, b0, acc[jb][0]);
+            acc[jb][1] = mfma_f64(a, b1, acc[jb][1]);
+          }
         }
       }
     }
@@ -121,20 +138,42 @@ __device__ __forceinline__ void tile_mma(const double* __restrict__ As, const do
 
 // ------------------------------------------------------------------------------------------------
 // Left-looking supernodal update of one 128-row tile of a target panel:
-//   P_s[tile, :] -= sum over combos (d, rows ta..tb of d)  L_d[ta:tb, :] * L_d[p0:p1, :]^T
+//   P_s[tile, :] -= sum over combos (d, rows ta..ta+nt of d)  L_d[ta:ta+nt, :] * L_d[p0:p0+nq, :]^T
 // Rows/columns of each descendant are gathered into TARGET coordinates inside LDS, so the
-// accumulators stay in registers across all descendants.  MFMA-bound for the dense blocks.
+// accumulators stay in registers across all descendants.  The K dimension (columns of all descendants,
+// concatenated) is streamed in chunks of KC through a double-buffered LDS image: the global loads of
+// chunk i+1 are in flight in registers while chunk i feeds the MFMAs; one barrier per chunk.
+// A work item is (tile, combo range [cb,ce), slot): slot < 0 subtracts straight into the panel,
+// slot >= 0 writes the partial product to scratch (split-K; folded in by k_potrf / k_trsm loads).
+struct ComboDesc {
+  int64_t loff;     // L offset of the descendant panel
+  int64_t rowoff;   // offset of its row list in sn_rows
+  int32_t md, wd;   // panel rows (leading dimension) and width (K extent)
+  int32_t ta, nt;   // descendant rows [ta, ta+nt) land in this tile
+  int32_t p0, nq;   // descendant rows [p0, p0+nq) are the target's columns
+  int32_t ip0;      // >= 0: rows land at consecutive tile positions ip0..; -1: look each one up
+  int32_t jp0;      // >= 0: columns land at consecutive target columns jp0..; -1: look each one up
+};
+
+struct UpdWork {
+  int32_t tile;
+  int32_t slot;     // partial-slot index or -1
+  int64_t cb, ce;   // combo range
+};
+
 template <bool MFMA>
-__global__ __launch_bounds__(256) void k_update(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L) {
-  __shared__ __attribute__((aligned(16))) double As[KC * LDA];
-  __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
-  __shared__ int32_t rowlab[TM];
-  __shared__ int32_t ipos[TM];
-  __shared__ int32_t jpos[NB];
+__global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restrict__ work,
+                                                const ComboDesc* __restrict__ combos, double* __restrict__ L,
+                                                double* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Abuf = smem;                         // [2][KC*LDA]
+  double* Bbuf = smem + 2 * KC * LDA;          // [2][KC*LDB]
+  int32_t* rowlab = (int32_t*)(smem + 2 * KC * LDA + 2 * KC * LDB);  // [TM]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int32_t g = tiles[blockIdx.x];
-  const int64_t cb = S.combo_ptr[g], ce = S.combo_ptr[g + 1];
-  if (cb == ce) return;
+  const UpdWork wk = work[blockIdx.x];
+  const int32_t g = wk.tile;
+  const int64_t cb = wk.cb, ce = wk.ce;
+  if (cb >= ce) return;
   const int32_t s = S.tile_front[g];
   const int32_t ti = (int32_t)(g - S.tile_base[s]);
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
@@ -144,79 +183,184 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const int32_t* __restr
   const int32_t nrow = min(TM, m - R0);
   const int ncb = (w + 15) >> 4;
   if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
+  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += 256) smem[idx] = 0.0;
   d4 acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  // this thread's fixed roles in the staging: A row t with k parity kpa; B column q with k phase kpb
+  const int t = tid & 127, kpa = tid >> 7;
+  const int q = tid & 63, kpb = tid >> 6;
+  // per-buffer record of what this thread wrote (so that it can clear exactly that)
+  int w_ip[2] = {-1, -1}, w_jp[2] = {-1, -1}, w_kc[2] = {0, 0};
+  // "next chunk" cursor
+  int64_t cn = cb;
+  int k0n = 0;
+  ComboDesc dn = combos[cn];
+  int ipn = -1, jpn = -1;
+  auto locate = [&]() {
+    // tile position of this thread's descendant row / target column for combo dn
+    ipn = -1;
+    jpn = -1;
+    if (t < dn.nt) {
+      if (dn.ip0 >= 0) {
+        ipn = dn.ip0 + t;
+      } else {
+        const int32_t lab = S.sn_rows[dn.rowoff + dn.ta + t];
+        int lo = 0, hi = nrow;
+        while (lo < hi) {
+          int mid = (lo + hi) >> 1;
+          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
+        }
+        ipn = lo;
+      }
+    }
+    if (q < dn.nq) jpn = (dn.jp0 >= 0) ? dn.jp0 + q : S.sn_rows[dn.rowoff + dn.p0 + q] - c0;
+  };
+  double ra[KC / 2], rb[KC / 4];
+  int kcn = 0;
+  auto prefetch = [&]() {
+    kcn = min(KC, dn.wd - k0n);
+    const double* Pd = L + dn.loff + (int64_t)k0n * dn.md;
+    const int64_t md = dn.md;
+    if (ipn >= 0) {
+      const double* pa = Pd + (int64_t)kpa * md + dn.ta + t;
+      if (kcn == KC) {
+#pragma unroll
+        for (int i = 0; i < KC / 2; ++i) ra[i] = pa[(int64_t)(2 * i) * md];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KC / 2; ++i) ra[i] = (kpa + 2 * i < kcn) ? pa[(int64_t)(2 * i) * md] : 0.0;
+      }
+    }
+    if (jpn >= 0) {
+      const double* pb = Pd + (int64_t)kpb * md + dn.p0 + q;
+      if (kcn == KC) {
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i) rb[i] = pb[(int64_t)(4 * i) * md];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i) rb[i] = (kpb + 4 * i < kcn) ? pb[(int64_t)(4 * i) * md] : 0.0;
+      }
+    }
+  };
+  // uniform (per-workgroup) record of the mapping last staged into each buffer
+  int u_ip0[2] = {-2, -2}, u_nt[2] = {0, 0}, u_jp0[2] = {-2, -2}, u_nq[2] = {0, 0}, u_kc[2] = {0, 0};
+  auto stage = [&](int b) {
+    double* As = Abuf + b * KC * LDA;
+    double* Bs = Bbuf + b * KC * LDB;
+    // The cells a thread writes belong to the descendant row/column it carries, so when the mapping of
+    // the incoming chunk differs from what the buffer holds, every thread first clears its own old cells
+    // and a barrier separates the clears from the new writes (another thread may now own that cell).
+    // Consecutive chunks of the dense chains share one mapping: no clear, no extra barrier.
+    const bool same = dn.ip0 >= 0 && dn.ip0 == u_ip0[b] && dn.nt == u_nt[b] && dn.jp0 >= 0 && dn.jp0 == u_jp0[b] &&
+                      dn.nq == u_nq[b] && kcn >= u_kc[b];
+    if (!same) {
+      if (w_ip[b] >= 0) {
+#pragma unroll
+        for (int i = 0; i < KC / 2; ++i) {
+          const int k = kpa + 2 * i;
+          if (k < w_kc[b]) As[k * LDA + w_ip[b]] = 0.0;
+        }
+      }
+      if (w_jp[b] >= 0) {
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i) {
+          const int k = kpb + 4 * i;
+          if (k < w_kc[b]) Bs[k * LDB + w_jp[b]] = 0.0;
+        }
+      }
+      __syncthreads();
+    }
+    if (ipn >= 0) {
+      double* wa = As + kpa * LDA + ipn;
+      if (kcn == KC) {
+#pragma unroll
+        for (int i = 0; i < KC / 2; ++i) wa[2 * i * LDA] = ra[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KC / 2; ++i)
+          if (kpa + 2 * i < kcn) wa[2 * i * LDA] = ra[i];
+      }
+    }
+    if (jpn >= 0) {
+      double* wb = Bs + kpb * LDB + jpn;
+      if (kcn == KC) {
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i) wb[4 * i * LDB] = rb[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KC / 4; ++i)
+          if (kpb + 4 * i < kcn) wb[4 * i * LDB] = rb[i];
+      }
+    }
+    w_ip[b] = ipn;
+    w_jp[b] = jpn;
+    w_kc[b] = kcn;
+    u_ip0[b] = dn.ip0;
+    u_nt[b] = dn.nt;
+    u_jp0[b] = dn.jp0;
+    u_nq[b] = dn.nq;
+    u_kc[b] = kcn;
+  };
+  auto advance = [&]() -> bool {
+    // move the cursor to the chunk after (cn, k0n); returns false at the end
+    k0n += KC;
+    if (k0n >= dn.wd) {
+      ++cn;
+      k0n = 0;
+      if (cn >= ce) return false;
+      dn = combos[cn];
+      locate();
+    }
+    return true;
+  };
+  __syncthreads();  // rowlab + zeroed buffers visible
+  locate();
+  prefetch();
+  stage(0);
+  int kc4_cur = (kcn + 3) & ~3;
+  bool more = advance();
   __syncthreads();
-  for (int64_t c = cb; c < ce; ++c) {
-    const int32_t e = S.combo_pair[c];
-    const int32_t d = S.upd_src[e], p0 = S.upd_p0[e], p1 = S.upd_p1[e];
-    const int32_t ta = S.combo_ta[c], tb = S.combo_tb[c];
-    const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
-    const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
-    const int32_t wd = S.sn_start[d + 1] - S.sn_start[d];
-    const double* Pd = L + S.sn_loff[d];
-    const int32_t nt = tb - ta, nq = p1 - p0;
-    __syncthreads();  // previous combo's compute is done with ipos/jpos/As/Bs
-    if (tid < nt) {
-      const int32_t lab = rd[ta + tid];
-      int lo = 0, hi = nrow;
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
-      }
-      ipos[tid] = lo;
-    } else if (tid >= 128 && tid - 128 < nq) {
-      jpos[tid - 128] = rd[p0 + tid - 128] - c0;
-    }
-    const bool fullA = (nt == nrow), fullB = (nq == w);
-    for (int32_t k0 = 0; k0 < wd; k0 += KC) {
-      const int kc = min(KC, wd - k0);
-      const int kc4 = (kc + 3) & ~3;
-      if (k0 > 0) __syncthreads();  // compute of the previous chunk finished
-      // rows of the LDS images that this chunk does not overwrite must read as zero
-      if (!fullA) {
-        for (int idx = tid; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
-      } else {
-        for (int idx = tid + kc * LDA; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
-      }
-      if (!fullB) {
-        for (int idx = tid; idx < kc4 * LDB; idx += 256) Bs[idx] = 0.0;
-      } else {
-        for (int idx = tid + kc * LDB; idx < kc4 * LDB; idx += 256) Bs[idx] = 0.0;
-      }
-      __syncthreads();
-      {
-        const int t = tid & 127;
-        if (t < nt) {
-          const int ip = ipos[t];
-          for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + ip] = Pd[(int64_t)(k0 + k) * md + ta + t];
-        }
-        const int q = tid & 63;
-        if (q < nq) {
-          const int jp = jpos[q];
-          for (int k = tid >> 6; k < kc; k += 4) Bs[k * LDB + jp] = Pd[(int64_t)(k0 + k) * md + p0 + q];
-        }
-      }
-      __syncthreads();
-      if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
-    }
+  int buf = 0;
+  while (true) {
+    if (more) prefetch();  // global loads of the next chunk in flight during the MFMAs
+    if (32 * wv < nrow) tile_mma<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, ncb, lane, wv, acc);
+    if (!more) break;
+    stage(buf ^ 1);
+    kc4_cur = (kcn + 3) & ~3;
+    more = advance();
+    __syncthreads();
+    buf ^= 1;
   }
-  // epilogue: D[M=j][N=i] -> panel(R0+i, j); 16 consecutive lanes hit 128 contiguous bytes of a column
-  double* P = L + S.sn_loff[s];
+  // epilogue: D[M=j][N=i] -> panel(R0+i, j) (or the partial slot); 16 consecutive lanes = 128 contiguous bytes
   const int li = lane & 15, lr = lane >> 4;
+  if (wk.slot < 0) {
+    double* P = L + S.sn_loff[s];
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb)
+    for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
+      for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * jb + lr + 4 * r;
-        const int i = 32 * wv + 16 * ib + li;
-        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][ib][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jb + lr + 4 * r;
+          const int i = 32 * wv + 16 * ib + li;
+          if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][ib][r];
+        }
+  } else {
+    double* Q = scratch + (int64_t)wk.slot * (TM * NB);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jb + lr + 4 * r;
+          const int i = 32 * wv + 16 * ib + li;
+          Q[j * TM + i] = acc[jb][ib][r];
+        }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -224,7 +368,9 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const int32_t* __restr
 // inverse (so every later triangular solve with this block is an MFMA GEMM) and sum(log diag).
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                double* __restrict__ invD, double* __restrict__ logd,
-                                               int32_t* __restrict__ status) {
+                                               int32_t* __restrict__ status, const int32_t* __restrict__ tile_pslot,
+                                               const int32_t* __restrict__ tile_pnseg,
+                                               const double* __restrict__ scratch) {
   constexpr int LD = NB + 1;
   __shared__ double Ls[NB * LD];
   __shared__ double Xs[NB * LD];
@@ -233,9 +379,17 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   double* P = L + S.sn_loff[s];
+  // split-K partial products of the update kernel for tile 0 (the diagonal block lives in tile 0: w <= TM)
+  const int64_t g0 = S.tile_base[s];
+  const int32_t ps = tile_pslot[g0], pn = tile_pnseg[g0];
   for (int idx = tid; idx < w * w; idx += 256) {
     const int k = idx / w, i = idx - k * w;
-    Ls[i * LD + k] = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
+    double v = 0.0;
+    if (i >= k) {
+      v = P[(int64_t)k * m + i];
+      for (int sg = 0; sg < pn; ++sg) v -= scratch[(int64_t)(ps + sg) * (TM * NB) + k * TM + i];
+    }
+    Ls[i * LD + k] = v;
     Xs[i * LD + k] = 0.0;
   }
   __syncthreads();
@@ -290,7 +444,9 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
 //   P[i, :] <- P[i, :] * invL^T   for the rows i >= w of a 128-row tile.   D[M=j][N=i].
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
-                                              const double* __restrict__ invD) {
+                                              const double* __restrict__ invD, const int32_t* __restrict__ tile_pslot,
+                                              const int32_t* __restrict__ tile_pnseg,
+                                              const double* __restrict__ scratch) {
   __shared__ __attribute__((aligned(16))) double As[KC * LDA];
   __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -305,6 +461,7 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
   const int ncb = (w + 15) >> 4;
   double* P = L + S.sn_loff[s];
   const double* I = invD + S.inv_off[s];
+  const int32_t ps = tile_pslot[g], pn = tile_pnseg[g];
   d4 acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -320,7 +477,20 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
     {
       const int t = tid & 127;
       if (t < nrow)
-        for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + t] = P[(int64_t)(k0 + k) * m + R0 + t];
+        for (int k = tid >> 7; k < kc; k += 2) {
+          double v = P[(int64_t)(k0 + k) * m + R0 + t];
+          const double* sp = scratch + (int64_t)ps * (TM * NB) + (k0 + k) * TM + t;
+          double v1 = 0.0, v2 = 0.0, v3 = 0.0;
+          int sg = 0;
+          for (; sg + 4 <= pn; sg += 4) {  // four independent loads in flight; fixed order => reproducible
+            v -= sp[(int64_t)(sg) * (TM * NB)];
+            v1 -= sp[(int64_t)(sg + 1) * (TM * NB)];
+            v2 -= sp[(int64_t)(sg + 2) * (TM * NB)];
+            v3 -= sp[(int64_t)(sg + 3) * (TM * NB)];
+          }
+          for (; sg < pn; ++sg) v -= sp[(int64_t)sg * (TM * NB)];
+          As[k * LDA + t] = v + ((v1 + v2) + v3);
+        }
       const int q = tid & 63;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
       if (q < w)
         for (int k = tid >> 6; k < kc; k += 4) Bs[k * LDB + q] = I[(k0 + k) * w + q];

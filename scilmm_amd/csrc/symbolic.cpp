@@ -546,6 +546,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     S->upd_src.resize(nu);
     S->upd_p0.resize(nu);
     S->upd_p1.resize(nu);
+    S->upd_jp0.resize(nu);
     std::vector<int64_t> fill(S->upd_ptr.begin(), S->upd_ptr.end() - 1);
     for (int32_t d = 0; d < ns; ++d) {  // increasing d => each target's list is in increasing descendant order
       int64_t rb = S->sn_rowptr[d], re = S->sn_rowptr[d + 1];
@@ -559,6 +560,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         S->upd_src[f] = d;
         S->upd_p0[f] = (int32_t)(t - rb);
         S->upd_p1[f] = (int32_t)(t2 - rb);
+        S->upd_jp0[f] = (S->sn_rows[t2 - 1] - S->sn_rows[t] == (int32_t)(t2 - 1 - t)) ? S->sn_rows[t] - out[s].start : -1;
         {
           const double nq = (double)(t2 - t), below = (double)(re - t2);
           S->update_flops += (double)w * (nq * (nq + 1.0) + 2.0 * nq * below);
@@ -600,6 +602,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         S->combo_pair.resize(cnt[nt]);
         S->combo_ta.resize(cnt[nt]);
         S->combo_tb.resize(cnt[nt]);
+        S->combo_ip0.resize(cnt[nt]);
         fill.assign(cnt.begin(), cnt.end() - 1);
       }
 #pragma omp parallel for schedule(dynamic, 64)
@@ -628,6 +631,8 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
               S->combo_pair[f] = (int32_t)e;
               S->combo_ta[f] = t;
               S->combo_tb[f] = t2;
+              const int64_t pos_last = std::lower_bound(rs + pos, rs + ms, rd[t2 - 1]) - rs;
+              S->combo_ip0[f] = (pos_last - pos == (int64_t)(t2 - 1 - t)) ? (int32_t)(pos - tile * TM) : -1;
             }
             t = t2;
           }

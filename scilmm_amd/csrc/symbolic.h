@@ -56,6 +56,8 @@ struct Symbolic {
   std::vector<int64_t> combo_ptr;   // [ntiles+1]
   std::vector<int32_t> combo_pair;  // index into upd_src/upd_p0/upd_p1
   std::vector<int32_t> combo_ta, combo_tb;
+  std::vector<int32_t> combo_ip0;   // tile position of row ta when rows ta..tb land on consecutive positions, else -1
+  std::vector<int32_t> upd_jp0;     // [npairs] target column of row p0 when rows p0..p1 are consecutive columns, else -1
   std::vector<int64_t> level_tile_ptr; // [nlevels+1] tiles of level l are level_tiles[ptr[l]..ptr[l+1])
   std::vector<int32_t> level_tiles;    // global tile ids sorted by level (heaviest first)
   std::vector<int64_t> level_pair_ptr; // [nlevels+1] update pairs whose TARGET is in level l
