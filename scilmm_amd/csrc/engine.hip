@@ -48,7 +48,20 @@ struct Dev {
   int32_t* d_tile_pslot = nullptr;
   int32_t* d_tile_pnseg = nullptr;
   double* scratch = nullptr;       // max slots per level * TM*NB doubles
+  int32_t* d_red_tiles = nullptr;  // tiles that carry partial slabs, grouped by level
+  // cell-wise path for small update pairs
+  int64_t* d_cell_dst = nullptr;
+  int64_t* d_cell_grp = nullptr;
+  int64_t* d_cell_srct = nullptr;
+  int64_t* d_cell_srcq = nullptr;
+  int32_t* d_cell_md = nullptr;
+  int32_t* d_cell_wd = nullptr;
+  std::vector<int64_t> cell_level_ptr;  // [nlevels+1] over unique target cells
+  std::vector<int64_t> cell_level_short; // [nlevels] number of short groups (listed first) in each level
+  int64_t n_dense_combos = 0, n_sparse_combos = 0, n_cells = 0;
+  std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
+  int ablate = 0;
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   std::vector<hipEvent_t> pev;     // 4 events per level when profiling
 };
@@ -111,6 +124,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   for (auto& e : D->ev) HIPCHK(hipEventCreate(&e));
   const char* nm = getenv("SCILMM_NO_MFMA");
   D->use_mfma = !(nm && nm[0] == '1');
+  const char* ab = getenv("SCILMM_ABLATE");
+  D->ablate = ab ? atoi(ab) : 0;
   D->v.n = S.n;
   D->v.nsuper = S.nsuper;
   int st;
@@ -149,22 +164,106 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   // ---- update-kernel plan
   {
     const int64_t nc = (int64_t)S.combo_pair.size();
-    std::vector<ComboDesc> cd((size_t)std::max<int64_t>(nc, 1));
-    for (int64_t c = 0; c < nc; ++c) {
-      const int32_t e = S.combo_pair[c];
-      const int32_t d = S.upd_src[e];
-      ComboDesc& x = cd[c];
-      x.loff = S.sn_loff[d];
-      x.rowoff = S.sn_rowptr[d];
-      x.md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
-      x.wd = S.sn_start[d + 1] - S.sn_start[d];
-      x.ta = S.combo_ta[c];
-      x.nt = S.combo_tb[c] - S.combo_ta[c];
-      x.p0 = S.upd_p0[e];
-      x.nq = S.upd_p1[e] - S.upd_p0[e];
-      x.ip0 = S.combo_ip0[c];
-      x.jp0 = S.upd_jp0[e];
+    const int64_t ntiles0 = (int64_t)S.tile_front.size();
+    const char* ecs = getenv("SCILMM_CELL_LIMIT");
+    const double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
+    std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
+    std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0);
+    struct Cell { int64_t dst, st, sq; int32_t md, wd, level; };
+    std::vector<Cell> cells;
+    cd.reserve((size_t)nc / 2 + 16);
+    for (int64_t g = 0; g < ntiles0; ++g) {
+      const int32_t sfr = S.tile_front[g];
+      const int32_t ti = (int32_t)(g - S.tile_base[sfr]);
+      const int32_t c0s = S.sn_start[sfr];
+      const int64_t ms = S.sn_rowptr[sfr + 1] - S.sn_rowptr[sfr];
+      const int32_t* rs = S.sn_rows.data() + S.sn_rowptr[sfr];
+      const int64_t R0 = (int64_t)ti * TM;
+      const int64_t tile_end = std::min<int64_t>(R0 + TM, ms);
+      for (int64_t c = S.combo_ptr[g]; c < S.combo_ptr[g + 1]; ++c) {
+        const int32_t e = S.combo_pair[c];
+        const int32_t d = S.upd_src[e];
+        ComboDesc x;
+        x.loff = S.sn_loff[d];
+        x.rowoff = S.sn_rowptr[d];
+        x.md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+        x.wd = S.sn_start[d + 1] - S.sn_start[d];
+        x.ta = S.combo_ta[c];
+        x.nt = S.combo_tb[c] - S.combo_ta[c];
+        x.p0 = S.upd_p0[e];
+        x.nq = S.upd_p1[e] - S.upd_p0[e];
+        x.ip0 = S.combo_ip0[c];
+        x.jp0 = S.upd_jp0[e];
+        if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
+          cd.push_back(x);
+          continue;
+        }
+        D->n_sparse_combos++;
+        const int32_t* rd = S.sn_rows.data() + x.rowoff;
+        const int32_t* lo = rs + R0;
+        for (int32_t t = x.ta; t < x.ta + x.nt; ++t) {
+          const int64_t R = (x.ip0 >= 0) ? R0 + x.ip0 + (t - x.ta) : (std::lower_bound(lo, rs + tile_end, rd[t]) - rs);
+          for (int32_t q = x.p0; q < x.p0 + x.nq; ++q) {
+            const int64_t j = rd[q] - c0s;
+            if (R < j) continue;  // strict upper part of the diagonal block is never referenced
+            cells.push_back(Cell{S.sn_loff[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr]});
+          }
+        }
+      }
+      dptr[g + 1] = (int64_t)cd.size();
     }
+    D->n_dense_combos = (int64_t)cd.size();
+    D->n_cells = (int64_t)cells.size();
+    std::sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) {
+      if (a.level != b.level) return a.level < b.level;
+      if (a.dst != b.dst) return a.dst < b.dst;
+      if (a.st != b.st) return a.st < b.st;
+      return a.sq < b.sq;
+    });
+    {
+      // groups of cells sharing one target address; inside a level the short groups come first
+      struct Grp { int64_t dst, b, e; int32_t level; };
+      std::vector<Grp> groups;
+      for (size_t i = 0; i < cells.size(); ++i) {
+        if (i == 0 || cells[i].dst != cells[i - 1].dst || cells[i].level != cells[i - 1].level)
+          groups.push_back(Grp{cells[i].dst, (int64_t)i, (int64_t)i, cells[i].level});
+        groups.back().e = (int64_t)i + 1;
+      }
+      const int64_t long_limit = 16;
+      std::stable_sort(groups.begin(), groups.end(), [&](const Grp& a, const Grp& b) {
+        if (a.level != b.level) return a.level < b.level;
+        const bool la = (a.e - a.b) > long_limit, lb = (b.e - b.b) > long_limit;
+        return la < lb;
+      });
+      std::vector<int64_t> udst, grp, st_, sq_;
+      std::vector<int32_t> md_, wd_;
+      D->cell_level_ptr.assign(S.nlevels + 1, 0);
+      D->cell_level_short.assign(S.nlevels, 0);
+      st_.reserve(cells.size()); sq_.reserve(cells.size()); md_.reserve(cells.size()); wd_.reserve(cells.size());
+      for (const Grp& G : groups) {
+        udst.push_back(G.dst);
+        grp.push_back((int64_t)st_.size());
+        D->cell_level_ptr[G.level + 1]++;
+        if (G.e - G.b <= long_limit) D->cell_level_short[G.level]++;
+        for (int64_t i = G.b; i < G.e; ++i) {
+          st_.push_back(cells[i].st); sq_.push_back(cells[i].sq); md_.push_back(cells[i].md); wd_.push_back(cells[i].wd);
+        }
+      }
+      grp.push_back((int64_t)st_.size());
+      for (int32_t l = 0; l < S.nlevels; ++l) D->cell_level_ptr[l + 1] += D->cell_level_ptr[l];
+      if (getenv("SCILMM_VERBOSE"))
+        fprintf(stderr, "[scilmm plan] dense combos %lld, cell-path combos %lld, cells %lld in %lld target groups\n",
+                (long long)D->n_dense_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)groups.size());
+      std::vector<Cell>().swap(cells);
+      const int64_t* t64; const int32_t* t32;
+      if ((st = upload(sym, D, udst, &t64)) != SCILMM_OK) return st; D->d_cell_dst = (int64_t*)t64;
+      if ((st = upload(sym, D, grp, &t64)) != SCILMM_OK) return st; D->d_cell_grp = (int64_t*)t64;
+      if ((st = upload(sym, D, st_, &t64)) != SCILMM_OK) return st; D->d_cell_srct = (int64_t*)t64;
+      if ((st = upload(sym, D, sq_, &t64)) != SCILMM_OK) return st; D->d_cell_srcq = (int64_t*)t64;
+      if ((st = upload(sym, D, md_, &t32)) != SCILMM_OK) return st; D->d_cell_md = (int32_t*)t32;
+      if ((st = upload(sym, D, wd_, &t32)) != SCILMM_OK) return st; D->d_cell_wd = (int32_t*)t32;
+    }
+    if (cd.empty()) cd.push_back(ComboDesc{});
     const ComboDesc* dc;
     if ((st = upload(sym, D, cd, &dc)) != SCILMM_OK) return st;
     D->d_combos = (ComboDesc*)dc;
@@ -172,6 +271,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
     std::vector<UpdWork> work;
     D->work_ptr.assign(S.nlevels + 1, 0);
+    D->red_ptr.assign(S.nlevels + 1, 0);
+    std::vector<int32_t> red_tiles;
     int64_t max_slots = 0;
     const char* ens = getenv("SCILMM_NO_SPLITK");
     const bool allow_split = !(ens && ens[0] == '1');
@@ -184,7 +285,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       int64_t total = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
         const int32_t g = S.level_tiles[i];
-        for (int64_t c = S.combo_ptr[g]; c < S.combo_ptr[g + 1]; ++c) total += combo_cost(c);
+        for (int64_t c = dptr[g]; c < dptr[g + 1]; ++c) total += combo_cost(c);
       }
       const int64_t min_item = 24;  // below this the fixed cost of an item (LDS clear, 64 KB partial) dominates
       const int64_t per_item = allow_split ? std::max<int64_t>(min_item, (total + target_items - 1) / target_items)
@@ -192,7 +293,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       int64_t slots = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
         const int32_t g = S.level_tiles[i];
-        const int64_t cb = S.combo_ptr[g], ce = S.combo_ptr[g + 1];
+        const int64_t cb = dptr[g], ce = dptr[g + 1];
         if (ce == cb) continue;
         int64_t tcost = 0;
         for (int64_t c = cb; c < ce; ++c) tcost += combo_cost(c);
@@ -219,13 +320,18 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         } else {
           pslot[g] = (int32_t)slots;
           pnseg[g] = (int32_t)made;
+          red_tiles.push_back(g);
           for (int64_t k = 0; k < made; ++k) work[first + k].slot = (int32_t)(slots + k);
           slots += made;
         }
       }
       max_slots = std::max(max_slots, slots);
       D->work_ptr[l + 1] = (int64_t)work.size();
+      D->red_ptr[l + 1] = (int64_t)red_tiles.size();
     }
+    if (red_tiles.empty()) red_tiles.push_back(0);
+    if ((st = upload(sym, D, red_tiles, &tmp)) != SCILMM_OK) return st;
+    D->d_red_tiles = (int32_t*)tmp;
     if (work.empty()) work.push_back(UpdWork{0, -1, 0, 0});
     const UpdWork* dw;
     if ((st = upload(sym, D, work, &dw)) != SCILMM_OK) return st;
@@ -254,8 +360,10 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
   return SCILMM_OK;
 }
@@ -348,28 +456,51 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 0], st));
     const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
     if (w1 > w0) {
-      if (D->use_mfma)
-        hipLaunchKernelGGL(k_update<true>, dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
+      if (D->use_mfma && D->ablate == 1)
+        hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
+                           fac->L, D->scratch);
+      else if (D->use_mfma && D->ablate == 2)
+        hipLaunchKernelGGL((k_update<true, 2>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
+                           fac->L, D->scratch);
+      else if (D->use_mfma)
+        hipLaunchKernelGGL((k_update<true, 0>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
                            fac->L, D->scratch);
       else
-        hipLaunchKernelGGL(k_update<false>, dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
+        hipLaunchKernelGGL((k_update<false, 0>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
                            fac->L, D->scratch);
       launches++;
+    }
+    const int64_t r0 = D->red_ptr[l], r1 = D->red_ptr[l + 1];
+    if (r1 > r0) {
+      hipLaunchKernelGGL(k_reduce, dim3((unsigned)(16 * (r1 - r0))), dim3(128), 0, st, D->v, D->d_red_tiles + r0, D->d_tile_pslot,
+                         D->d_tile_pnseg, (const double*)D->scratch, fac->L);
+      launches++;
+    }
+    {
+      const int64_t u0 = D->cell_level_ptr[l], u1 = D->cell_level_ptr[l + 1];
+      if (u1 > u0) {
+        const int64_t nshort = D->cell_level_short[l], nlong = (u1 - u0) - nshort;
+        const int64_t nblk = (nshort + 255) / 256 + (nlong + 3) / 4;
+        hipLaunchKernelGGL(k_sparse_cells, dim3((unsigned)nblk), dim3(256), 0, st, u0, nshort, u1 - u0,
+                           (const int64_t*)D->d_cell_dst, (const int64_t*)D->d_cell_grp, (const int64_t*)D->d_cell_srct,
+                           (const int64_t*)D->d_cell_srcq, (const int32_t*)D->d_cell_md, (const int32_t*)D->d_cell_wd, fac->L);
+        launches++;
+      }
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 1], st));
     if (f1 > f0) {
       hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
-                         fac->invD, fac->logd, fac->status, D->d_tile_pslot, D->d_tile_pnseg, D->scratch);
+                         fac->invD, fac->logd, fac->status);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 2], st));
     if (t1 > t0) {
       if (D->use_mfma)
         hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
-                           fac->invD, D->d_tile_pslot, D->d_tile_pnseg, D->scratch);
+                           fac->invD);
       else
         hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
-                           fac->invD, D->d_tile_pslot, D->d_tile_pnseg, D->scratch);
+                           fac->invD);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 3], st));

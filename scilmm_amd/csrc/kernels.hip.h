@@ -161,7 +161,8 @@ struct UpdWork {
   int64_t cb, ce;   // combo range
 };
 
-template <bool MFMA>
+// ABL (diagnostic builds only, selected by SCILMM_ABLATE): 0 = real kernel, 1 = no MFMAs, 2 = no global loads.
+template <bool MFMA, int ABL = 0>
 __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restrict__ work,
                                                 const ComboDesc* __restrict__ combos, double* __restrict__ L,
                                                 double* __restrict__ scratch) {
@@ -224,6 +225,13 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
     kcn = min(KC, dn.wd - k0n);
     const double* Pd = L + dn.loff + (int64_t)k0n * dn.md;
     const int64_t md = dn.md;
+    if (ABL == 2) {
+#pragma unroll
+      for (int i = 0; i < KC / 2; ++i) ra[i] = 1.0e-3;
+#pragma unroll
+      for (int i = 0; i < KC / 4; ++i) rb[i] = 1.0e-3;
+      return;
+    }
     if (ipn >= 0) {
       const double* pa = Pd + (int64_t)kpa * md + dn.ta + t;
       if (kcn == KC) {
@@ -326,7 +334,8 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
   int buf = 0;
   while (true) {
     if (more) prefetch();  // global loads of the next chunk in flight during the MFMAs
-    if (32 * wv < nrow) tile_mma<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, ncb, lane, wv, acc);
+    if (ABL != 1 && 32 * wv < nrow)
+      tile_mma<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, ncb, lane, wv, acc);
     if (!more) break;
     stage(buf ^ 1);
     kc4_cur = (kcn + 3) & ~3;
@@ -364,77 +373,259 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense Cholesky of the w x w diagonal block of each front of a level, in LDS, plus its explicit
-// inverse (so every later triangular solve with this block is an MFMA GEMM) and sum(log diag).
+// Cell-wise path for the small update pairs (a few rows x a few columns of a narrow descendant): the host
+// groups every contributed target cell by address; one thread owns one target cell and subtracts the dot
+// products  sum_k L_d[t,k] L_d[q,k]  of all its contributions in a fixed order.  No LDS, no barriers, no
+// atomics, bitwise reproducible.  Integer/latency-bound gather work, kept off the MFMA pipeline.
+__device__ __forceinline__ double cell_dot(const double* __restrict__ L, int64_t st, int64_t sq, int64_t md, int wd) {
+  const double* pt = L + st;
+  const double* pq = L + sq;
+  double a0 = 0.0, a1 = 0.0;
+  int k = 0;
+  for (; k + 2 <= wd; k += 2) {
+    a0 += pt[k * md] * pq[k * md];
+    a1 += pt[(k + 1) * md] * pq[(k + 1) * md];
+  }
+  if (k < wd) a0 += pt[k * md] * pq[k * md];
+  return a0 + a1;
+}
+
+// groups [first, first+n_short) : one thread each;  groups [first+n_short, first+count) : one wave each
+__global__ __launch_bounds__(256) void k_sparse_cells(int64_t first, int64_t n_short, int64_t count,
+                                                      const int64_t* __restrict__ uniq_dst,
+                                                      const int64_t* __restrict__ grp_ptr,
+                                                      const int64_t* __restrict__ src_t,
+                                                      const int64_t* __restrict__ src_q,
+                                                      const int32_t* __restrict__ src_md,
+                                                      const int32_t* __restrict__ src_wd, double* __restrict__ L) {
+  const int64_t short_blocks = (n_short + 255) / 256;
+  if ((int64_t)blockIdx.x < short_blocks) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_short) return;
+    const int64_t g = first + u;
+    double acc = 0.0;
+    for (int64_t c = grp_ptr[g]; c < grp_ptr[g + 1]; ++c) acc += cell_dot(L, src_t[c], src_q[c], src_md[c], src_wd[c]);
+    L[uniq_dst[g]] -= acc;
+  } else {
+    const int lane = threadIdx.x & 63;
+    const int64_t u = n_short + ((int64_t)blockIdx.x - short_blocks) * 4 + (threadIdx.x >> 6);
+    if (u >= count) return;
+    const int64_t g = first + u;
+    double acc = 0.0;
+    for (int64_t c = grp_ptr[g] + lane; c < grp_ptr[g + 1]; c += 64) acc += cell_dot(L, src_t[c], src_q[c], src_md[c], src_wd[c]);
+    // fixed-shape butterfly: the same summation tree on every run
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) L[uniq_dst[g]] -= acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fold the split-K partial products of the update kernel into the panel:  P[tile] -= sum_seg part[seg].
+// One workgroup per (tile, 16-column group); thread = tile row.  Fixed summation order (reproducible).
+__global__ __launch_bounds__(128) void k_reduce(DevSym S, const int32_t* __restrict__ red_tiles,
+                                                const int32_t* __restrict__ tile_pslot,
+                                                const int32_t* __restrict__ tile_pnseg, const double* __restrict__ scratch,
+                                                double* __restrict__ L) {
+  const int32_t g = red_tiles[blockIdx.x >> 4];
+  const int jg = (blockIdx.x & 15) * 4;
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t w = S.sn_start[s + 1] - S.sn_start[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int t = threadIdx.x;
+  if (R0 + t >= m || jg >= w) return;
+  const int32_t ps = tile_pslot[g], pn = tile_pnseg[g];
+  double* P = L + S.sn_loff[s] + R0 + t + (int64_t)jg * m;
+  const double* sp = scratch + (int64_t)ps * (TM * NB) + jg * TM + t;
+  const int jend = min(4, w - jg);
+  double v[4], e[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = (u < jend) ? P[(int64_t)u * m] : 0.0;
+  // two interleaved accumulator sets keep 8 loads in flight; the order of additions is fixed
+  int sg = 0;
+  for (; sg + 2 <= pn; sg += 2) {
+    const double* q0 = sp + (int64_t)sg * (TM * NB);
+    const double* q1 = q0 + TM * NB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < jend) {
+        v[u] -= q0[u * TM];
+        e[u] -= q1[u * TM];
+      }
+  }
+  if (sg < pn) {
+    const double* q0 = sp + (int64_t)sg * (TM * NB);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < jend) v[u] -= q0[u * TM];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (u < jend) P[(int64_t)u * m] = v[u] + e[u];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense Cholesky of the w x w (w <= 64) diagonal block of each front of a level plus its explicit
+// inverse (every later triangular solve with this block becomes an MFMA GEMM) and sum(log diag).
+// Blocked by 16: the 16 x 16 diagonal blocks are factored and inverted by ONE wave in registers with
+// cross-lane shuffles (no barriers); panel solve, trailing update and the block recursion for the
+// inverse run on all 256 threads out of LDS.  ~30 barriers instead of ~200 + a 2000-step serial loop.
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                double* __restrict__ invD, double* __restrict__ logd,
-                                               int32_t* __restrict__ status, const int32_t* __restrict__ tile_pslot,
-                                               const int32_t* __restrict__ tile_pnseg,
-                                               const double* __restrict__ scratch) {
+                                               int32_t* __restrict__ status) {
   constexpr int LD = NB + 1;
   __shared__ double Ls[NB * LD];
   __shared__ double Xs[NB * LD];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t s = fronts[blockIdx.x];
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   double* P = L + S.sn_loff[s];
-  // split-K partial products of the update kernel for tile 0 (the diagonal block lives in tile 0: w <= TM)
-  const int64_t g0 = S.tile_base[s];
-  const int32_t ps = tile_pslot[g0], pn = tile_pnseg[g0];
-  for (int idx = tid; idx < w * w; idx += 256) {
-    const int k = idx / w, i = idx - k * w;
-    double v = 0.0;
-    if (i >= k) {
-      v = P[(int64_t)k * m + i];
-      for (int sg = 0; sg < pn; ++sg) v -= scratch[(int64_t)(ps + sg) * (TM * NB) + k * TM + i];
-    }
+  const int nb = (w + 15) >> 4, W = nb << 4;  // padded with an identity block
+  for (int idx = tid; idx < W * W; idx += 256) {
+    const int k = idx / W, i = idx - k * W;
+    double v = (i == k) ? 1.0 : 0.0;
+    if (i < w && k < w) v = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
     Ls[i * LD + k] = v;
     Xs[i * LD + k] = 0.0;
   }
   __syncthreads();
-  for (int j = 0; j < w; ++j) {
-    if (tid == 0) {
-      double dj = Ls[j * LD + j];
-      if (!(dj > 0.0) || !(dj < 1.0e300)) {
-        atomicMin(status, c0 + j);
-        dj = 1.0;
+  for (int kb = 0; kb < nb; ++kb) {
+    const int o = kb << 4;
+    if (wv == 0) {
+      // ---- 16 x 16 diagonal block in registers: lane r (mod 16) owns row r
+      const int r = lane & 15;
+      double a[16], x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = Ls[(o + r) * LD + o + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double v = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= a[k] * __shfl(a[k], j, 16);
+        double dj = __shfl(v, j, 16);
+        if (!(dj > 0.0) || !(dj < 1.0e300)) {
+          if (lane == 0) atomicMin(status, c0 + o + j);
+          dj = 1.0;
+        }
+        const double sd = sqrt(dj);
+        a[j] = (r == j) ? sd : ((r > j) ? v / sd : 0.0);
       }
-      Ls[j * LD + j] = sqrt(dj);
+      // inverse of the block: lane r owns COLUMN r of the inverse
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double sum = (r == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) sum -= __shfl(a[k], j, 16) * x[k];
+        const double djj = __shfl(a[j], j, 16);
+        x[j] = (j >= r) ? sum / djj : 0.0;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          Ls[(o + r) * LD + o + c] = a[c];
+          Xs[(o + c) * LD + o + r] = x[c];
+        }
+      }
     }
     __syncthreads();
-    const double inv = 1.0 / Ls[j * LD + j];
-    for (int i = j + 1 + tid; i < w; i += 256) Ls[i * LD + j] *= inv;
-    __syncthreads();
-    const int nrem = w - j - 1;
-    for (int idx = tid; idx < nrem * nrem; idx += 256) {
-      const int ii = idx / nrem, kk = idx - ii * nrem;
-      if (kk <= ii) {
-        const int i = j + 1 + ii, k = j + 1 + kk;
-        Ls[i * LD + k] -= Ls[i * LD + j] * Ls[k * LD + j];
+    const int nrem = W - o - 16;
+    if (nrem > 0) {
+      // ---- panel below: B = A * Dinv^T   (B[i][c] = sum_{k<=c} A[i][k] Dinv[c][k])
+      double tmp[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int idx = tid + 256 * q;
+        tmp[q] = 0.0;
+        if (idx < nrem * 16) {
+          const int i = o + 16 + (idx >> 4), c = idx & 15;
+          double sum = 0.0;
+          for (int k = 0; k <= c; ++k) sum += Ls[i * LD + o + k] * Xs[(o + c) * LD + o + k];
+          tmp[q] = sum;
+        }
       }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int idx = tid + 256 * q;
+        if (idx < nrem * 16) Ls[(o + 16 + (idx >> 4)) * LD + o + (idx & 15)] = tmp[q];
+      }
+      __syncthreads();
+      // ---- trailing update (lower part): A[i][k'] -= sum_c B[i][c] B[k'][c]
+      for (int idx = tid; idx < nrem * nrem; idx += 256) {
+        const int ii = idx / nrem, kk = idx - ii * nrem;
+        if (kk <= ii) {
+          const int i = o + 16 + ii, k2 = o + 16 + kk;
+          double sum = 0.0;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) sum += Ls[i * LD + o + c] * Ls[k2 * LD + o + c];
+          Ls[i * LD + k2] -= sum;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  // inverse of the lower-triangular block: thread c owns column c (uniform loops => broadcast reads)
-  if (tid < w) {
-    const int c = tid;
-    for (int j = 0; j < w; ++j) {
-      double sum = (j == c) ? 1.0 : 0.0;
-      for (int k = 0; k < j; ++k) sum -= Ls[j * LD + k] * Xs[k * LD + c];
-      Xs[j * LD + c] = (j >= c) ? sum / Ls[j * LD + j] : 0.0;
+  // ---- inverse of the whole block by block sub-diagonals: X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj
+  for (int d = 1; d < nb; ++d) {
+    const int nblk = nb - d;
+    double tmp[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 256 * q;
+      tmp[q] = 0.0;
+      if (idx < nblk * 256) {
+        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
+        const int i0 = (blk + d) << 4, j0 = blk << 4;
+        double sum = 0.0;
+        for (int kk = j0; kk < i0; ++kk) sum += Ls[(i0 + rr) * LD + kk] * Xs[kk * LD + j0 + cc];
+        tmp[q] = sum;
+      }
     }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < nblk * 256) {
+        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
+        Xs[(((blk + d) << 4) + rr) * LD + (blk << 4) + cc] = tmp[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 256 * q;
+      tmp[q] = 0.0;
+      if (idx < nblk * 256) {
+        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
+        const int i0 = (blk + d) << 4, j0 = blk << 4;
+        double sum = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) sum += Xs[(i0 + rr) * LD + i0 + kk] * Xs[(i0 + kk) * LD + j0 + cc];
+        tmp[q] = -sum;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < nblk * 256) {
+        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
+        Xs[(((blk + d) << 4) + rr) * LD + (blk << 4) + cc] = tmp[q];
+      }
+    }
+    __syncthreads();
   }
   if (tid == 64) {
     double sl = 0.0;
     for (int j = 0; j < w; ++j) sl += log(Ls[j * LD + j]);
     logd[s] = sl;
   }
-  __syncthreads();
   double* I = invD + S.inv_off[s];
   for (int idx = tid; idx < w * w; idx += 256) {
     const int k = idx / w, i = idx - k * w;
-    P[(int64_t)k * m + i] = Ls[i * LD + k];  // upper part was zeroed on load
+    P[(int64_t)k * m + i] = (i >= k) ? Ls[i * LD + k] : 0.0;
     I[k * w + i] = Xs[i * LD + k];
   }
 }
@@ -444,9 +635,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
 //   P[i, :] <- P[i, :] * invL^T   for the rows i >= w of a 128-row tile.   D[M=j][N=i].
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
-                                              const double* __restrict__ invD, const int32_t* __restrict__ tile_pslot,
-                                              const int32_t* __restrict__ tile_pnseg,
-                                              const double* __restrict__ scratch) {
+                                              const double* __restrict__ invD) {
   __shared__ __attribute__((aligned(16))) double As[KC * LDA];
   __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -461,7 +650,6 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
   const int ncb = (w + 15) >> 4;
   double* P = L + S.sn_loff[s];
   const double* I = invD + S.inv_off[s];
-  const int32_t ps = tile_pslot[g], pn = tile_pnseg[g];
   d4 acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -477,20 +665,7 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
     {
       const int t = tid & 127;
       if (t < nrow)
-        for (int k = tid >> 7; k < kc; k += 2) {
-          double v = P[(int64_t)(k0 + k) * m + R0 + t];
-          const double* sp = scratch + (int64_t)ps * (TM * NB) + (k0 + k) * TM + t;
-          double v1 = 0.0, v2 = 0.0, v3 = 0.0;
-          int sg = 0;
-          for (; sg + 4 <= pn; sg += 4) {  // four independent loads in flight; fixed order => reproducible
-            v -= sp[(int64_t)(sg) * (TM * NB)];
-            v1 -= sp[(int64_t)(sg + 1) * (TM * NB)];
-            v2 -= sp[(int64_t)(sg + 2) * (TM * NB)];
-            v3 -= sp[(int64_t)(sg + 3) * (TM * NB)];
-          }
-          for (; sg < pn; ++sg) v -= sp[(int64_t)sg * (TM * NB)];
-          As[k * LDA + t] = v + ((v1 + v2) + v3);
-        }
+        for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + t] = P[(int64_t)(k0 + k) * m + R0 + t];
       const int q = tid & 63;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
       if (q < w)
         for (int k = tid >> 6; k < kc; k += 4) Bs[k * LDB + q] = I[(k0 + k) * w + q];

@@ -1,0 +1,133 @@
+"""GPU parity of the full hot-path caller: REML / LMM / run_estimates through the HIP engine against
+(a) the golden trajectories produced by the reference's own Python (tests/golden) and (b) the oracle's
+independent restatement (oracle/reml_oracle.py) on fresh problems.
+
+Tolerances: nll relative 1e-9, gradient relative 1e-6 (fused single-sweep evaluation re-associates a few sums),
+sigma2 / beta / std-errors relative 1e-6 (north_star's bar), same permutation and same np.random stream.
+"""
+import importlib
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+from scipy.io import mmwrite
+
+from tests.helpers import rel_err, small_pedigree
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+P = importlib.import_module("scilmm_amd.SparseCholesky")
+M = importlib.import_module("scilmm_amd.Estimation.LMM")
+
+
+def _g1():
+    g = np.load(os.path.join(GOLD, "G1_reml_2000.npz"))
+    A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=tuple(g["A_shape"]))
+    return g, A
+
+
+def _record(mod):
+    trace = []
+    orig = mod.bolt_gradient_estimation
+
+    def rec(x, *a, **k):
+        nll, grad = orig(x, *a, **k)
+        trace.append((np.array(x), nll, np.array(grad)))
+        return nll, grad
+
+    mod.bolt_gradient_estimation = rec
+    return trace, orig
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("tag", ["amd", "ident"])
+def test_reml_reproduces_reference_trajectory(tag, fused):
+    g, A = _g1()
+    chol = P.SparseCholesky(perm=g["%s_perm" % tag], fused=fused)
+    trace, orig = _record(P)
+    try:
+        np.random.seed(1)
+        res = P.REML(chol, [A], g["C"], g["y"].copy())
+    finally:
+        P.bolt_gradient_estimation = orig
+    nref = len(g["%s_nll" % tag])
+    assert abs(len(trace) - nref) <= 2
+    for i in range(min(len(trace), nref)):
+        x, nll, grad = trace[i]
+        assert rel_err(x, g["%s_x" % tag][i]) < 1e-6, i
+        assert abs(nll - g["%s_nll" % tag][i]) < 1e-9 * abs(g["%s_nll" % tag][i]), i
+        assert rel_err(grad, g["%s_grad" % tag][i]) < 1e-5, i
+    assert rel_err(res["covariance coefficients"], g["%s_sigma2" % tag]) < 1e-6
+    assert rel_err(res["covariates coefficients"], g["%s_beta" % tag]) < 1e-6
+    assert rel_err(res["covariance std"], g["%s_std" % tag]) < 1e-6
+
+
+def test_ml_evaluation_matches_reference_golden():
+    g, A = _g1()
+    n = A.shape[0]
+    chol = P.SparseCholesky(perm=g["amd_perm"])
+    np.random.seed(3)
+    nll, grad = P.bolt_gradient_estimation(np.log([0.3, 0.7]), chol, [A, sp.eye(n).tocsr()], g["C"], g["y"] / g["y"].std(),
+                                           False, 100, False)
+    assert abs(nll - float(g["ml_nll"])) < 1e-10 * abs(float(g["ml_nll"]))
+    assert rel_err(grad, g["ml_grad"]) < 1e-7
+
+
+def test_lmm_three_components_reproduces_reference():
+    g, A = _g1()
+    g2 = np.load(os.path.join(GOLD, "G2_lmm_dominance.npz"))
+    D = sp.csr_matrix((g2["D_data"], g2["D_indices"], g2["D_indptr"]), shape=A.shape)
+    np.random.seed(2)
+    res = M.LMM(M.SparseCholesky(perm=g2["perm"]), [A, D], g2["cov"], g["y"].copy())
+    assert rel_err(res["covariance coefficients"], g2["sigma2"]) < 1e-5
+    assert rel_err(res["covariates coefficients"], g2["beta"]) < 1e-5
+    assert rel_err(res["covariance std"], g2["std"]) < 1e-4
+    assert rel_err(res["covariates p-values"], g2["pvalues"]) < 1e-5
+
+
+def test_evaluation_vs_oracle_with_engine_ordering():
+    """Fresh pedigree, engine's own AMD ordering; the oracle factors V with the engine's P."""
+    from oracle import reml_oracle as RO
+    A, sex = small_pedigree(5000, 0.005, 4)
+    n = A.shape[0]
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(n)
+    C = np.stack([(sex - sex.mean()) / sex.std(), np.ones(n)], axis=1)
+    mats = [A, sp.eye(n).tocsr()]
+    chol = P.SparseCholesky()
+    perm = chol.engine_for(mats).P()
+    for reml in (True, False):
+        x = np.log([0.35, 0.55])
+        np.random.seed(9)
+        nll, grad = P.bolt_gradient_estimation(x, chol, mats, C, y, reml, 100, False)
+        np.random.seed(9)
+        nll_o, grad_o = RO.evaluate(x, mats, C, y, reml, 100, perm=perm)
+        assert abs(nll - nll_o) < 1e-10 * abs(nll_o)
+        assert rel_err(grad, grad_o) < 1e-7
+
+
+def test_cli_round_trip(tmp_path, capsys):
+    g, A = _g1()
+    n = A.shape[0]
+    mmwrite(str(tmp_path / "A.mtx"), A)
+    pd.DataFrame({"iid": np.arange(n), "y": g["y"]}).to_csv(tmp_path / "y.csv", header=False, index=False)
+    sexcol = (g["C"][:, 0] > 0).astype(float)
+    pd.DataFrame({"IID": np.arange(n), "sex": sexcol}).to_csv(tmp_path / "c.csv", index=False)
+    np.random.seed(1)
+    out = P._main(["--A", str(tmp_path / "A.mtx"), "--phe", str(tmp_path / "y.csv"), "--cov", str(tmp_path / "c.csv"), "--reml"])
+    s2 = out["covariance coefficients"]
+    assert s2.shape == (2,) and np.all(s2 > 0)
+    # same data, same covariates (z-scored sex + intercept) => the estimates agree with the golden fit to MC accuracy
+    assert abs(s2[0] / s2.sum() - g["amd_sigma2"][0] / g["amd_sigma2"].sum()) < 0.05
+    he = P._main(["--A", str(tmp_path / "A.mtx"), "--phe", str(tmp_path / "y.csv"), "--cov", str(tmp_path / "c.csv")])
+    assert rel_err(he[0], g["he_est"]) < 1e-8
+    assert "HE estimates are" in capsys.readouterr().out
+
+
+def test_not_positive_definite_surfaces_as_exception():
+    from scilmm_amd import NotPositiveDefiniteError
+    V = sp.csr_matrix(np.array([[1.0, 3.0], [3.0, 1.0]]))
+    with pytest.raises(NotPositiveDefiniteError):
+        P.SparseCholesky(ordering_method="natural")(V)

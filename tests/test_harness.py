@@ -1,0 +1,57 @@
+"""CPU tests of the synthetic-pedigree harness against the reference's own IBD / dominance arithmetic (goldens)."""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from scilmm_amd.harness import pedigree as H
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _parents(rel):
+    rel = sp.csr_matrix(rel)
+    n = rel.shape[0]
+    par = np.full((n, 2), -1, dtype=np.int64)
+    for i in range(n):
+        p = rel.indices[rel.indptr[i]:rel.indptr[i + 1]]
+        par[i, :p.size] = np.sort(p)
+    return par
+
+
+def test_ibd_matches_reference_on_its_fixture():
+    g = np.load(os.path.join(GOLD, "G0_relationship_example.npz"))
+    A, L, D = H.ibd_from_parents(_parents(g["rel"]), return_LD=True)
+    assert np.array_equal(A.toarray(), g["A"])
+    assert np.array_equal(L.toarray(), g["L"])
+    assert np.array_equal(D, np.diag(g["D"]))
+
+
+def test_ibd_and_dominance_match_reference_on_simulated_pedigree():
+    g1 = np.load(os.path.join(GOLD, "G1_reml_2000.npz"))
+    g2 = np.load(os.path.join(GOLD, "G2_lmm_dominance.npz"))
+    shape = tuple(g1["A_shape"])
+    A = sp.csr_matrix((g1["A_data"], g1["A_indices"], g1["A_indptr"]), shape=shape)
+    rel = sp.csr_matrix((g2["rel_data"], g2["rel_indices"], g2["rel_indptr"]), shape=shape)
+    Dref = sp.csr_matrix((g2["D_data"], g2["D_indices"], g2["D_indptr"]), shape=shape)
+    Dm = H.dominance_from_parents(_parents(rel), A)
+    assert abs(Dm - Dref).max() < 1e-14
+
+
+def test_generator_statistics():
+    par, sex, gen = H.simulate_pedigree(3000, 0.005, seed=1)
+    assert np.all(par[par[:, 0] >= 0, 0] < np.where(par[:, 0] >= 0)[0])  # parents precede children
+    A = H.ibd_from_parents(par)
+    assert abs(A.nnz - 3000 ** 2 * 0.005) < 0.1 * 3000 ** 2 * 0.005
+    assert abs(A - A.T).max() < 1e-14
+    assert A.diagonal().min() >= 1.0
+    A2, has = H.drop_unrelated(A)[:2]
+    assert np.all(np.asarray(A2.sum(axis=1)).ravel() > 1)
+    assert list(H.generation_sizes(100, 1.4)[:4]) == [2, 2, 3, 5]
+
+
+def test_make_problem_shapes():
+    mats, C, y = H.make_problem(2000, 0.005, seed=0)
+    n = mats[0].shape[0]
+    assert C.shape == (n, 2) and y.shape == (n,)
+    assert abs(C[:, 0].mean()) < 1e-12 and abs(C[:, 0].std() - 1) < 1e-12 and np.all(C[:, 1] == 1)

@@ -1,0 +1,108 @@
+"""CPU tests of the host symbolic phase (ordering, etree, column counts, supernodes, schedules) through the C-ABI."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from scilmm_amd.factor import Symbolic
+from tests.helpers import random_spd
+
+
+def _boolean_cholesky(M, perm):
+    Pm = M[perm][:, perm].toarray()
+    S = Pm != 0
+    n = S.shape[0]
+    for k in range(n):
+        r = np.where(S[k + 1:, k])[0] + k + 1
+        S[np.ix_(r, r)] = True
+    return np.tril(S)
+
+
+@pytest.mark.parametrize("ordering", ["amd", "natural"])
+def test_exact_structure_without_relaxation(ordering):
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        n = int(rng.integers(5, 110))
+        M = random_spd(n, float(rng.uniform(0.02, 0.3)), trial)
+        sym = Symbolic([M], ordering=ordering, upload=False, relax_small=0, relax_w1=0, relax_w2=0, relax_z3=0.0)
+        perm = sym.get("perm")
+        assert sorted(perm.tolist()) == list(range(n))
+        S = _boolean_cholesky(M, perm)
+        assert np.array_equal(S.sum(axis=0), sym.get("colcount"))
+        info = sym.info()
+        assert info.nnzL == S.sum()
+        assert info.flops == float((S.sum(axis=0).astype(float) ** 2).sum())
+        st, rp, rows = sym.get("sn_start"), sym.get("sn_rowptr"), sym.get("sn_rows")
+        for s in range(info.nsuper):
+            assert np.array_equal(rows[rp[s]:rp[s + 1]], np.where(S[:, st[s]])[0])
+            assert st[s + 1] - st[s] <= 64
+
+
+def test_relaxed_supernodes_cover_true_structure_and_schedules_are_consistent():
+    rng = np.random.default_rng(1)
+    for trial in range(8):
+        n = int(rng.integers(20, 300))
+        M = random_spd(n, float(rng.uniform(0.02, 0.2)), 100 + trial)
+        sym = Symbolic([M, sp.identity(n, format="csr")], upload=False)
+        perm = sym.get("perm")
+        S = _boolean_cholesky(M, perm)
+        st, rp, rows = sym.get("sn_start"), sym.get("sn_rowptr"), sym.get("sn_rows")
+        lev, par = sym.get("sn_level"), sym.get("sn_parent")
+        ns = sym.info().nsuper
+        for s in range(ns):
+            rr = set(rows[rp[s]:rp[s + 1]].tolist())
+            for j in range(st[s], st[s + 1]):
+                assert set(np.where(S[:, j])[0].tolist()) <= rr
+            if par[s] >= 0:
+                assert lev[par[s]] > lev[s] and par[s] > s
+        # every update pair (target s <- descendant d) targets a strictly higher level
+        up, src, p0, p1 = sym.get("upd_ptr"), sym.get("upd_src"), sym.get("upd_p0"), sym.get("upd_p1")
+        for s in range(ns):
+            for e in range(up[s], up[s + 1]):
+                d = src[e]
+                assert lev[d] < lev[s]
+                rd = rows[rp[d]:rp[d + 1]]
+                assert np.all((rd[p0[e]:p1[e]] >= st[s]) & (rd[p0[e]:p1[e]] < st[s + 1]))
+        # combos tile the rows of every pair exactly once
+        cp, pair, ta, tb = sym.get("combo_ptr"), sym.get("combo_pair"), sym.get("combo_ta"), sym.get("combo_tb")
+        covered = np.zeros(len(src), dtype=np.int64)
+        for c in range(cp[-1]):
+            covered[pair[c]] += tb[c] - ta[c]
+        md = (rp[1:] - rp[:-1])[src]
+        assert np.array_equal(covered, md - p0)
+
+
+def test_user_permutation_is_honoured_exactly():
+    M = random_spd(80, 0.1, 7)
+    perm = np.random.default_rng(2).permutation(80)
+    sym = Symbolic([M], perm=perm, upload=False)
+    assert np.array_equal(sym.get("perm"), perm)
+    assert np.array_equal(_boolean_cholesky(M, perm).sum(axis=0), sym.get("colcount"))
+
+
+def test_invalid_permutation_is_rejected():
+    from scilmm_amd._lib import ScilmmError
+    M = random_spd(10, 0.3, 8)
+    with pytest.raises(ScilmmError):
+        Symbolic([M], perm=np.zeros(10, dtype=np.int32), upload=False)
+
+
+def test_amd_fill_is_close_to_superlu_mmd_on_a_pedigree():
+    import scipy.sparse.linalg as sla
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(4000, 0.01, 3)
+    n = A.shape[0]
+    sym = Symbolic([A, sp.identity(n, format="csr")], upload=False)
+    lu = sla.splu((0.5 * A + 0.5 * sp.identity(n)).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0,
+                  options={"SymmetricMode": True})
+    assert sym.info().nnzL < 1.15 * lu.L.nnz
+    nat = Symbolic([A, sp.identity(n, format="csr")], ordering="natural", upload=False)
+    assert sym.info().nnzL < 0.6 * nat.info().nnzL
+
+
+def test_empty_and_diagonal_inputs():
+    I = sp.identity(5, format="csr")
+    sym = Symbolic([I], upload=False)
+    info = sym.info()
+    assert info.nnzL == 5 and info.n_updates == 0
+    one = sp.csr_matrix(np.array([[2.0]]))
+    assert Symbolic([one], upload=False).info().nnzL == 1
