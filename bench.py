@@ -124,7 +124,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    prof = {"update_ms": 0.0, "potrf_ms": 0.0, "trsm_ms": 0.0, "assemble_ms": 0.0, "factor_ms": 0.0,
+    prof = {"update_ms": 0.0, "potrf_ms": 0.0, "trsm_ms": 0.0, "reduce_cells_ms": 0.0, "assemble_ms": 0.0, "factor_ms": 0.0,
             "solve_fwd_ms": 0.0, "solve_bwd_ms": 0.0, "n_update_launches": 0, "n_launches": 0}
     for i in range(args.steps):
         step(i)
@@ -175,7 +175,7 @@ def main():
                        "solve_ms": (prof["solve_fwd_ms"] + prof["solve_bwd_ms"]) / K,
                        "solve_fwd_ms": prof["solve_fwd_ms"] / K, "solve_bwd_ms": prof["solve_bwd_ms"] / K,
                        "update_ms": prof["update_ms"] / K, "potrf_ms": prof["potrf_ms"] / K,
-                       "trsm_ms": prof["trsm_ms"] / K, "launches_per_factorize": prof["n_launches"] / K,
+                       "trsm_ms": prof["trsm_ms"] / K, "reduce_cells_ms": prof["reduce_cells_ms"] / K, "launches_per_factorize": prof["n_launches"] / K,
                        "symbolic_s": t_sym, "generate_s": t_gen, "logdet": logdet_total, "solve_residual": resid},
             "roofline": {"bound": "mfma", "kernel": "k_update<true> (fp64 MFMA supernodal update)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

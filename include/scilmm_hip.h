@@ -109,6 +109,7 @@ typedef struct scilmm_timing {
   /* filled when profiling is on: HIP-event time summed per kernel class over the last factorize */
   double update_ms, potrf_ms, trsm_ms;
   int64_t n_update_launches;
+  double reduce_cells_ms;
 } scilmm_timing;
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
 /* Bracket every kernel class of the factorization with HIP events on the handle's stream (bench.py's

@@ -50,7 +50,7 @@ class Timing(C.Structure):
     _fields_ = [("assemble_ms", C.c_double), ("factor_ms", C.c_double), ("solve_fwd_ms", C.c_double),
                 ("solve_bwd_ms", C.c_double), ("lmul_ms", C.c_double), ("quad_ms", C.c_double),
                 ("n_launches", C.c_int64), ("update_ms", C.c_double), ("potrf_ms", C.c_double),
-                ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64)]
+                ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64), ("reduce_cells_ms", C.c_double)]
 
 
 # every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)

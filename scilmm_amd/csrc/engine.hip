@@ -44,20 +44,29 @@ struct Dev {
   // update-kernel plan: flattened combo descriptors, per-level work items (split-K), partial slots
   ComboDesc* d_combos = nullptr;
   UpdWork* d_work = nullptr;
-  std::vector<int64_t> work_ptr;   // [nlevels+1]
+  std::vector<int64_t> work_ptr;   // [nlevels+1] LATE items (descendants one level below the target): main stream
+  UpdWork* d_work_early = nullptr; // EARLY items (older descendants): side stream, overlaps the previous level
+  std::vector<int64_t> early_ptr;  // [nlevels+1]
+  int64_t max_slots = 0;           // partial slabs per scratch half (scratch is double-buffered by level parity)
+  hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
+  std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
+  hipEvent_t ev_asm = nullptr;
   int32_t* d_tile_pslot = nullptr;
   int32_t* d_tile_pnseg = nullptr;
   double* scratch = nullptr;       // max slots per level * TM*NB doubles
   int32_t* d_red_tiles = nullptr;  // tiles that carry partial slabs, grouped by level
-  // cell-wise path for small update pairs
-  int64_t* d_cell_dst = nullptr;
-  int64_t* d_cell_grp = nullptr;
-  int64_t* d_cell_srct = nullptr;
-  int64_t* d_cell_srcq = nullptr;
-  int32_t* d_cell_md = nullptr;
-  int32_t* d_cell_wd = nullptr;
-  std::vector<int64_t> cell_level_ptr;  // [nlevels+1] over unique target cells
-  std::vector<int64_t> cell_level_short; // [nlevels] number of short groups (listed first) in each level
+  // cell-wise path for small update pairs: set 0 = early (side stream), set 1 = late (main stream)
+  struct CellSet {
+    int64_t* dst = nullptr;
+    int64_t* grp = nullptr;
+    int64_t* srct = nullptr;
+    int64_t* srcq = nullptr;
+    int32_t* md = nullptr;
+    int32_t* wd = nullptr;
+    std::vector<int64_t> level_ptr;    // [nlevels+1] over unique target cells
+    std::vector<int64_t> level_short;  // [nlevels] short groups (listed first) per level
+  } cellset[2];
   int64_t n_dense_combos = 0, n_sparse_combos = 0, n_cells = 0;
   std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
@@ -101,6 +110,11 @@ void dev_free(void* p) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : D->pev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : D->lev_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (D->ev_asm) (void)hipEventDestroy(D->ev_asm);
+  if (D->side) (void)hipStreamDestroy(D->side);
+  if (D->side2) (void)hipStreamDestroy(D->side2);
   if (D->stream) (void)hipStreamDestroy(D->stream);
   delete D;
 }
@@ -120,7 +134,18 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   sym->device_free = dev_free;
   for (auto& e : D->ev) e = nullptr;
   const Symbolic& S = *sym->S;
-  HIPCHK(hipStreamCreate(&D->stream));
+  {
+    // the main stream carries the latency-bound per-level chain: give it dispatch priority over the side
+    // stream that streams the look-ahead updates
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&D->stream, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
+  }
+  HIPCHK(hipEventCreateWithFlags(&D->ev_asm, hipEventDisableTiming));
+  D->lev_ev.assign((size_t)2 * std::max(S.nlevels, 1), nullptr);
+  for (auto& e : D->lev_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : D->ev) HIPCHK(hipEventCreate(&e));
   const char* nm = getenv("SCILMM_NO_MFMA");
   D->use_mfma = !(nm && nm[0] == '1');
@@ -168,8 +193,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* ecs = getenv("SCILMM_CELL_LIMIT");
     const double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
     std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
-    std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0);
-    struct Cell { int64_t dst, st, sq; int32_t md, wd, level; };
+    std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
+    const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
+    const bool lookahead = !(ela && ela[0] == '1');
+    std::vector<ComboDesc> late_tmp;
+    struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };
     std::vector<Cell> cells;
     cd.reserve((size_t)nc / 2 + 16);
     for (int64_t g = 0; g < ntiles0; ++g) {
@@ -195,7 +223,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         x.ip0 = S.combo_ip0[c];
         x.jp0 = S.upd_jp0[e];
         if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
-          cd.push_back(x);
+          // "late" = the descendant sits one level below the target (finished only just before this level)
+          if (!lookahead || S.sn_level[d] + 1 == S.sn_level[sfr]) late_tmp.push_back(x); else cd.push_back(x);
           continue;
         }
         D->n_sparse_combos++;
@@ -206,62 +235,75 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           for (int32_t q = x.p0; q < x.p0 + x.nq; ++q) {
             const int64_t j = rd[q] - c0s;
             if (R < j) continue;  // strict upper part of the diagonal block is never referenced
-            cells.push_back(Cell{S.sn_loff[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr]});
+            cells.push_back(Cell{S.sn_loff[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr],
+                                 (!lookahead || S.sn_level[d] + 1 == S.sn_level[sfr]) ? 1 : 0});
           }
         }
       }
+      dmid[g] = (int64_t)cd.size();
+      cd.insert(cd.end(), late_tmp.begin(), late_tmp.end());
+      late_tmp.clear();
       dptr[g + 1] = (int64_t)cd.size();
     }
     D->n_dense_combos = (int64_t)cd.size();
     D->n_cells = (int64_t)cells.size();
     std::sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) {
+      if (a.late != b.late) return a.late < b.late;
       if (a.level != b.level) return a.level < b.level;
       if (a.dst != b.dst) return a.dst < b.dst;
       if (a.st != b.st) return a.st < b.st;
       return a.sq < b.sq;
     });
     {
-      // groups of cells sharing one target address; inside a level the short groups come first
-      struct Grp { int64_t dst, b, e; int32_t level; };
-      std::vector<Grp> groups;
-      for (size_t i = 0; i < cells.size(); ++i) {
-        if (i == 0 || cells[i].dst != cells[i - 1].dst || cells[i].level != cells[i - 1].level)
-          groups.push_back(Grp{cells[i].dst, (int64_t)i, (int64_t)i, cells[i].level});
-        groups.back().e = (int64_t)i + 1;
-      }
-      const int64_t long_limit = 16;
-      std::stable_sort(groups.begin(), groups.end(), [&](const Grp& a, const Grp& b) {
-        if (a.level != b.level) return a.level < b.level;
-        const bool la = (a.e - a.b) > long_limit, lb = (b.e - b.b) > long_limit;
-        return la < lb;
-      });
-      std::vector<int64_t> udst, grp, st_, sq_;
-      std::vector<int32_t> md_, wd_;
-      D->cell_level_ptr.assign(S.nlevels + 1, 0);
-      D->cell_level_short.assign(S.nlevels, 0);
-      st_.reserve(cells.size()); sq_.reserve(cells.size()); md_.reserve(cells.size()); wd_.reserve(cells.size());
-      for (const Grp& G : groups) {
-        udst.push_back(G.dst);
-        grp.push_back((int64_t)st_.size());
-        D->cell_level_ptr[G.level + 1]++;
-        if (G.e - G.b <= long_limit) D->cell_level_short[G.level]++;
-        for (int64_t i = G.b; i < G.e; ++i) {
-          st_.push_back(cells[i].st); sq_.push_back(cells[i].sq); md_.push_back(cells[i].md); wd_.push_back(cells[i].wd);
+      size_t split = 0;
+      while (split < cells.size() && cells[split].late == 0) ++split;
+      int64_t ngroups_total = 0;
+      for (int which = 0; which < 2; ++which) {
+        const size_t cb0 = which == 0 ? 0 : split, ce0 = which == 0 ? split : cells.size();
+        // groups of cells sharing one target address; inside a level the short groups come first
+        struct Grp { int64_t dst, b, e; int32_t level; };
+        std::vector<Grp> groups;
+        for (size_t i = cb0; i < ce0; ++i) {
+          if (i == cb0 || cells[i].dst != cells[i - 1].dst || cells[i].level != cells[i - 1].level)
+            groups.push_back(Grp{cells[i].dst, (int64_t)i, (int64_t)i, cells[i].level});
+          groups.back().e = (int64_t)i + 1;
         }
+        const int64_t long_limit = 16;
+        std::stable_sort(groups.begin(), groups.end(), [&](const Grp& a, const Grp& b) {
+          if (a.level != b.level) return a.level < b.level;
+          const bool la = (a.e - a.b) > long_limit, lb = (b.e - b.b) > long_limit;
+          return la < lb;
+        });
+        std::vector<int64_t> udst, grp, st_, sq_;
+        std::vector<int32_t> md_, wd_;
+        Dev::CellSet& CS = D->cellset[which];
+        CS.level_ptr.assign(S.nlevels + 1, 0);
+        CS.level_short.assign(std::max(S.nlevels, 1), 0);
+        for (const Grp& G : groups) {
+          udst.push_back(G.dst);
+          grp.push_back((int64_t)st_.size());
+          CS.level_ptr[G.level + 1]++;
+          if (G.e - G.b <= long_limit) CS.level_short[G.level]++;
+          for (int64_t i = G.b; i < G.e; ++i) {
+            st_.push_back(cells[i].st); sq_.push_back(cells[i].sq); md_.push_back(cells[i].md); wd_.push_back(cells[i].wd);
+          }
+        }
+        grp.push_back((int64_t)st_.size());
+        for (int32_t l = 0; l < S.nlevels; ++l) CS.level_ptr[l + 1] += CS.level_ptr[l];
+        ngroups_total += (int64_t)groups.size();
+        const int64_t* t64; const int32_t* t32;
+        if ((st = upload(sym, D, udst, &t64)) != SCILMM_OK) return st; CS.dst = (int64_t*)t64;
+        if ((st = upload(sym, D, grp, &t64)) != SCILMM_OK) return st; CS.grp = (int64_t*)t64;
+        if ((st = upload(sym, D, st_, &t64)) != SCILMM_OK) return st; CS.srct = (int64_t*)t64;
+        if ((st = upload(sym, D, sq_, &t64)) != SCILMM_OK) return st; CS.srcq = (int64_t*)t64;
+        if ((st = upload(sym, D, md_, &t32)) != SCILMM_OK) return st; CS.md = (int32_t*)t32;
+        if ((st = upload(sym, D, wd_, &t32)) != SCILMM_OK) return st; CS.wd = (int32_t*)t32;
       }
-      grp.push_back((int64_t)st_.size());
-      for (int32_t l = 0; l < S.nlevels; ++l) D->cell_level_ptr[l + 1] += D->cell_level_ptr[l];
       if (getenv("SCILMM_VERBOSE"))
-        fprintf(stderr, "[scilmm plan] dense combos %lld, cell-path combos %lld, cells %lld in %lld target groups\n",
-                (long long)D->n_dense_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)groups.size());
+        fprintf(stderr, "[scilmm plan] dense combos %lld, cell-path combos %lld, cells %lld (early %lld) in %lld target groups\n",
+                (long long)D->n_dense_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
+                (long long)ngroups_total);
       std::vector<Cell>().swap(cells);
-      const int64_t* t64; const int32_t* t32;
-      if ((st = upload(sym, D, udst, &t64)) != SCILMM_OK) return st; D->d_cell_dst = (int64_t*)t64;
-      if ((st = upload(sym, D, grp, &t64)) != SCILMM_OK) return st; D->d_cell_grp = (int64_t*)t64;
-      if ((st = upload(sym, D, st_, &t64)) != SCILMM_OK) return st; D->d_cell_srct = (int64_t*)t64;
-      if ((st = upload(sym, D, sq_, &t64)) != SCILMM_OK) return st; D->d_cell_srcq = (int64_t*)t64;
-      if ((st = upload(sym, D, md_, &t32)) != SCILMM_OK) return st; D->d_cell_md = (int32_t*)t32;
-      if ((st = upload(sym, D, wd_, &t32)) != SCILMM_OK) return st; D->d_cell_wd = (int32_t*)t32;
     }
     if (cd.empty()) cd.push_back(ComboDesc{});
     const ComboDesc* dc;
@@ -269,65 +311,80 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->d_combos = (ComboDesc*)dc;
     const int64_t ntiles = (int64_t)S.tile_front.size();
     std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
-    std::vector<UpdWork> work;
+    std::vector<UpdWork> work, work_early;
     D->work_ptr.assign(S.nlevels + 1, 0);
+    D->early_ptr.assign(S.nlevels + 1, 0);
     D->red_ptr.assign(S.nlevels + 1, 0);
     std::vector<int32_t> red_tiles;
     int64_t max_slots = 0;
     const char* ens = getenv("SCILMM_NO_SPLITK");
     const bool allow_split = !(ens && ens[0] == '1');
-    // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Every level is cut
-    // into work items of about total_cost / (4 workgroups per CU) so that one launch fills the chip once
-    // with balanced items (the late levels of a dense chain have few tiles but long combo lists).
+    // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Each launch (the early
+    // and the late part of a level) is cut into about 4 work items per CU of equal cost, so that one launch
+    // fills the chip once with balanced items (late levels of a dense chain: few tiles, long combo lists).
     auto combo_cost = [&](int64_t c) -> int64_t { return 1 + (cd[c].wd + KC - 1) / KC; };
-    const int64_t target_items = 1024;
+    const int64_t target_items = 1024, min_item = 24;
+    // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
+    auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
+      if (ce <= cb) return 0;
+      int64_t tcost = 0;
+      for (int64_t c = cb; c < ce; ++c) tcost += combo_cost(c);
+      const int64_t nseg = std::min<int64_t>(64, std::max<int64_t>(1, (tcost + per_item / 2) / per_item));
+      const int64_t seg_cost = (tcost + nseg - 1) / nseg;
+      const size_t first = out.size();
+      int64_t a = cb, acc = 0;
+      for (int64_t c = cb; c < ce; ++c) {
+        acc += combo_cost(c);
+        if (nseg > 1 && acc >= seg_cost && c + 1 < ce) {
+          out.push_back(UpdWork{g, 0, a, c + 1});
+          a = c + 1;
+          acc = 0;
+        }
+      }
+      out.push_back(UpdWork{g, 0, a, ce});
+      return (int64_t)(out.size() - first);
+    };
     for (int32_t l = 0; l < S.nlevels; ++l) {
-      int64_t total = 0;
+      int64_t total_e = 0, total_l = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
         const int32_t g = S.level_tiles[i];
-        for (int64_t c = dptr[g]; c < dptr[g + 1]; ++c) total += combo_cost(c);
+        for (int64_t c = dptr[g]; c < dmid[g]; ++c) total_e += combo_cost(c);
+        for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost(c);
       }
-      const int64_t min_item = 24;  // below this the fixed cost of an item (LDS clear, 64 KB partial) dominates
-      const int64_t per_item = allow_split ? std::max<int64_t>(min_item, (total + target_items - 1) / target_items)
-                                           : (int64_t)1 << 60;
+      const int64_t big = (int64_t)1 << 60;
+      const int64_t per_e = allow_split ? std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items) : big;
+      const int64_t per_l = allow_split ? std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items) : big;
       int64_t slots = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
         const int32_t g = S.level_tiles[i];
-        const int64_t cb = dptr[g], ce = dptr[g + 1];
-        if (ce == cb) continue;
-        int64_t tcost = 0;
-        for (int64_t c = cb; c < ce; ++c) tcost += combo_cost(c);
-        int64_t nseg = std::min<int64_t>(64, std::max<int64_t>(1, (tcost + per_item / 2) / per_item));
-        if (nseg == 1) {
-          work.push_back(UpdWork{g, -1, cb, ce});
-          continue;
-        }
-        const int64_t seg_cost = (tcost + nseg - 1) / nseg;
-        const size_t first = work.size();
-        int64_t a = cb, acc = 0;
-        for (int64_t c = cb; c < ce; ++c) {
-          acc += combo_cost(c);
-          if (acc >= seg_cost && c + 1 < ce) {
-            work.push_back(UpdWork{g, 0, a, c + 1});
-            a = c + 1;
-            acc = 0;
-          }
-        }
-        work.push_back(UpdWork{g, 0, a, ce});
-        const int64_t made = (int64_t)(work.size() - first);
-        if (made == 1) {
-          work[first].slot = -1;
-        } else {
+        const size_t fe = work_early.size(), fl = work.size();
+        const int64_t ne = cut(g, dptr[g], dmid[g], per_e, work_early);
+        const int64_t nl = cut(g, dmid[g], dptr[g + 1], per_l, work);
+        // a single item of a launch subtracts straight into the panel (the early and the late launch of a
+        // level never overlap in time); two or more items of one launch go through partial slabs
+        const int64_t pe = ne >= 2 ? ne : 0, pl = nl >= 2 ? nl : 0;
+        if (ne == 1) work_early[fe].slot = -1;
+        if (nl == 1) work[fl].slot = -1;
+        if (pe + pl > 0) {
           pslot[g] = (int32_t)slots;
-          pnseg[g] = (int32_t)made;
+          pnseg[g] = (int32_t)(pe + pl);
           red_tiles.push_back(g);
-          for (int64_t k = 0; k < made; ++k) work[first + k].slot = (int32_t)(slots + k);
-          slots += made;
+          for (int64_t k = 0; k < pe; ++k) work_early[fe + k].slot = (int32_t)(slots + k);
+          for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + pe + k);
+          slots += pe + pl;
         }
       }
       max_slots = std::max(max_slots, slots);
       D->work_ptr[l + 1] = (int64_t)work.size();
+      D->early_ptr[l + 1] = (int64_t)work_early.size();
       D->red_ptr[l + 1] = (int64_t)red_tiles.size();
+    }
+    D->max_slots = std::max<int64_t>(max_slots, 1);
+    if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
+    {
+      const UpdWork* dwe;
+      if ((st = upload(sym, D, work_early, &dwe)) != SCILMM_OK) return st;
+      D->d_work_early = (UpdWork*)dwe;
     }
     if (red_tiles.empty()) red_tiles.push_back(0);
     if ((st = upload(sym, D, red_tiles, &tmp)) != SCILMM_OK) return st;
@@ -341,7 +398,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     if ((st = upload(sym, D, pnseg, &tmp)) != SCILMM_OK) return st;
     D->d_tile_pnseg = (int32_t*)tmp;
     void* sc = nullptr;
-    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)std::max<int64_t>(max_slots, 1) * TM * NB));
+    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)2 * (size_t)D->max_slots * TM * NB));
     D->allocs.push_back(sc);
     D->scratch = (double*)sc;
   }
@@ -444,56 +501,88 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     launches++;
   }
   HIPCHK(hipEventRecord(D->ev[1], st));
+  HIPCHK(hipEventRecord(D->ev_asm, st));
+  HIPCHK(hipStreamWaitEvent(D->side, D->ev_asm, 0));
+  HIPCHK(hipStreamWaitEvent(D->side2, D->ev_asm, 0));
   const bool prof = D->profiling;
-  if (prof && D->pev.size() < (size_t)4 * S.nlevels) {
+  constexpr int PE = 8;  // profiling events per level
+  if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
     size_t old = D->pev.size();
-    D->pev.resize((size_t)4 * S.nlevels, nullptr);
+    D->pev.resize((size_t)PE * S.nlevels, nullptr);
     for (size_t i = old; i < D->pev.size(); ++i) HIPCHK(hipEventCreate(&D->pev[i]));
+  }
+  auto launch_update = [&](hipStream_t stream, const UpdWork* work, int64_t cnt, double* scratch_half) {
+    if (D->use_mfma && D->ablate == 1)
+      hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+    else if (D->use_mfma && D->ablate == 2)
+      hipLaunchKernelGGL((k_update<true, 2>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+    else if (D->use_mfma)
+      hipLaunchKernelGGL((k_update<true, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+    else
+      hipLaunchKernelGGL((k_update<false, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+    launches++;
+  };
+  const size_t half = (size_t)D->max_slots * TM * NB;
+  auto launch_cells = [&](hipStream_t stream, int which, int32_t l) {
+    const Dev::CellSet& CS = D->cellset[which];
+    const int64_t u0 = CS.level_ptr[l], u1 = CS.level_ptr[l + 1];
+    if (u1 <= u0) return;
+    const int64_t nshort = CS.level_short[l], nlong = (u1 - u0) - nshort;
+    const int64_t nblk = (nshort + 255) / 256 + (nlong + 3) / 4;
+    hipLaunchKernelGGL(k_sparse_cells, dim3((unsigned)nblk), dim3(256), 0, stream, u0, nshort, u1 - u0, (const int64_t*)CS.dst,
+                       (const int64_t*)CS.grp, (const int64_t*)CS.srct, (const int64_t*)CS.srcq, (const int32_t*)CS.md,
+                       (const int32_t*)CS.wd, fac->L);
+    launches++;
+  };
+  auto has_early = [&](int32_t l) -> bool {
+    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l];
+  };
+  // Look-ahead: the EARLY part of level l+1 (descendants finished at levels <= l-1) runs on the side stream
+  // while the main stream works through level l's latency-bound tail (late update, reduce, cells, potrf, trsm).
+  auto launch_early = [&](int32_t l) -> int {
+    const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
+    if (!has_early(l)) return SCILMM_OK;
+    hipStream_t sd = (l & 1) ? D->side2 : D->side;
+    if (l >= 2) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - 2)], 0));
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
+    if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)(l & 1) * half);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
+    launch_cells(sd, 0, l);  // early cells: same stream, after the early MFMA update of the same panels
+    HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
+    return SCILMM_OK;
+  };
+  {
+    int rc = S.nlevels > 1 ? launch_early(1) : SCILMM_OK;
+    if (rc != SCILMM_OK) return rc;
   }
   for (int32_t l = 0; l < S.nlevels; ++l) {
     const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
     const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
-    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 0], st));
-    const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
-    if (w1 > w0) {
-      if (D->use_mfma && D->ablate == 1)
-        hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
-                           fac->L, D->scratch);
-      else if (D->use_mfma && D->ablate == 2)
-        hipLaunchKernelGGL((k_update<true, 2>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
-                           fac->L, D->scratch);
-      else if (D->use_mfma)
-        hipLaunchKernelGGL((k_update<true, 0>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
-                           fac->L, D->scratch);
-      else
-        hipLaunchKernelGGL((k_update<false, 0>), dim3((unsigned)(w1 - w0)), dim3(256), sm_upd, st, D->v, D->d_work + w0, D->d_combos,
-                           fac->L, D->scratch);
-      launches++;
+    double* sh = D->scratch + (size_t)(l & 1) * half;
+    // early(l+1) may start as soon as level l-1 is finished: issue it before this level's own kernels
+    if (l >= 1 && l + 1 < S.nlevels) {
+      int rc = launch_early(l + 1);
+      if (rc != SCILMM_OK) return rc;
     }
+    if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
+    const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
+    if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
     const int64_t r0 = D->red_ptr[l], r1 = D->red_ptr[l + 1];
     if (r1 > r0) {
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)(16 * (r1 - r0))), dim3(128), 0, st, D->v, D->d_red_tiles + r0, D->d_tile_pslot,
-                         D->d_tile_pnseg, (const double*)D->scratch, fac->L);
+                         D->d_tile_pnseg, (const double*)sh, fac->L);
       launches++;
     }
-    {
-      const int64_t u0 = D->cell_level_ptr[l], u1 = D->cell_level_ptr[l + 1];
-      if (u1 > u0) {
-        const int64_t nshort = D->cell_level_short[l], nlong = (u1 - u0) - nshort;
-        const int64_t nblk = (nshort + 255) / 256 + (nlong + 3) / 4;
-        hipLaunchKernelGGL(k_sparse_cells, dim3((unsigned)nblk), dim3(256), 0, st, u0, nshort, u1 - u0,
-                           (const int64_t*)D->d_cell_dst, (const int64_t*)D->d_cell_grp, (const int64_t*)D->d_cell_srct,
-                           (const int64_t*)D->d_cell_srcq, (const int32_t*)D->d_cell_md, (const int32_t*)D->d_cell_wd, fac->L);
-        launches++;
-      }
-    }
-    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 1], st));
+    launch_cells(st, 1, l);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
     if (f1 > f0) {
       hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
                          fac->invD, fac->logd, fac->status);
       launches++;
     }
-    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 2], st));
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
     if (t1 > t0) {
       if (D->use_mfma)
         hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
@@ -503,13 +592,16 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
                            fac->invD);
       launches++;
     }
-    if (prof) HIPCHK(hipEventRecord(D->pev[4 * l + 3], st));
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
+    HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
   }
   HIPCHK(hipEventRecord(D->ev[2], st));
   HIPCHK(hipGetLastError());
   int32_t status = 0;
   HIPCHK(hipMemcpyAsync(&status, fac->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipStreamSynchronize(D->side));
+  HIPCHK(hipStreamSynchronize(D->side2));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));
@@ -517,20 +609,31 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   D->timing.factor_ms = f;
   D->timing.n_launches = launches;
   if (prof) {
-    double tu = 0, tp = 0, tt = 0;
+    double tu = 0, tp = 0, tt = 0, tmid = 0;
     int64_t nu = 0;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       float x = 0;
-      HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 0], D->pev[4 * l + 1]));
-      if (D->work_ptr[l + 1] > D->work_ptr[l]) { tu += x; nu++; }
-      HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 1], D->pev[4 * l + 2]));
+      if (D->work_ptr[l + 1] > D->work_ptr[l]) {
+        HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 0], D->pev[PE * l + 1]));
+        tu += x;
+        nu++;
+      }
+      if (D->early_ptr[l + 1] > D->early_ptr[l]) {
+        HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 5], D->pev[PE * l + 6]));
+        tu += x;
+        nu++;
+      }
+      HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 1], D->pev[PE * l + 2]));
+      tmid += x;
+      HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 2], D->pev[PE * l + 3]));
       tp += x;
-      HIPCHK(hipEventElapsedTime(&x, D->pev[4 * l + 2], D->pev[4 * l + 3]));
+      HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 3], D->pev[PE * l + 4]));
       tt += x;
     }
-    D->timing.update_ms = tu;
+    D->timing.update_ms = tu;       // sum of k_update launch durations (early + late; they overlap other kernels)
     D->timing.potrf_ms = tp;
     D->timing.trsm_ms = tt;
+    D->timing.reduce_cells_ms = tmid;
     D->timing.n_update_launches = nu;
   }
   if (status != 0x7fffffff) {

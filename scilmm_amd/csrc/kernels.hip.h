@@ -12,6 +12,12 @@
 //   lane l receives D[(l>>4) + 4*reg][l&15], reg = 0..3.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef SCILMM_KC
+#define SCILMM_KC 16
+#endif
+#ifndef SCILMM_UPD_WAVES
+#define SCILMM_UPD_WAVES 2
+#endif
 #include <stdint.h>
 
 namespace scilmm {
@@ -20,7 +26,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int NB = 64;        // max supernode block width (symbolic max_width must be <= NB)
 constexpr int TM = 128;       // target rows per tile
-constexpr int KC = 16;        // k-chunk staged through LDS (update kernel: 2 x 28 KB -> two workgroups per CU)
+constexpr int KC = SCILMM_KC;        // k-chunk staged through LDS (update kernel: 2 x 28 KB -> two workgroups per CU)
 constexpr int LDA = TM + 16;  // k-major LDS leading dims: (ld*8 B) == 128 mod 256 -> conflict-free b64 reads
 constexpr int LDB = NB + 16;
 constexpr int RPMAX = 128;    // max padded RHS columns per pass
@@ -161,9 +167,46 @@ struct UpdWork {
   int64_t cb, ce;   // combo range
 };
 
+constexpr int UPD_THREADS = 512;  // update kernel: eight waves per workgroup
+
+// Eight-wave variant of the tile product: wave wv owns 16 target rows, acc[jb] is the 16 x 16 tile of columns 16 jb..
+template <bool MFMA>
+__device__ __forceinline__ void tile_mma8(const double* __restrict__ As, const double* __restrict__ Bs, int kc4, int ncb,
+                                          int lane, int wv, d4 (&acc)[4]) {
+  const int li = lane & 15, lk = lane >> 4;
+  if (MFMA) {
+    const double* ap = As + lk * LDA + 16 * wv + li;
+    const double* bp = Bs + lk * LDB + li;
+    if (ncb == 4) {
+#pragma unroll 2
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        const double b0 = ap[k4 * LDA];
+        const double a0 = bp[k4 * LDB], a1 = bp[k4 * LDB + 16], a2 = bp[k4 * LDB + 32], a3 = bp[k4 * LDB + 48];
+        acc[0] = mfma_f64(a0, b0, acc[0]);
+        acc[1] = mfma_f64(a1, b0, acc[1]);
+        acc[2] = mfma_f64(a2, b0, acc[2]);
+        acc[3] = mfma_f64(a3, b0, acc[3]);
+      }
+    } else {
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        const double b0 = ap[k4 * LDA];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+          if (jb < ncb) acc[jb] = mfma_f64(bp[k4 * LDB + 16 * jb], b0, acc[jb]);
+      }
+    }
+  } else {
+    for (int k = 0; k < kc4; ++k)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][r] += Bs[k * LDB + 16 * jb + lk + 4 * r] * As[k * LDA + 16 * wv + li];
+  }
+}
+
 // ABL (diagnostic builds only, selected by SCILMM_ABLATE): 0 = real kernel, 1 = no MFMAs, 2 = no global loads.
 template <bool MFMA, int ABL = 0>
-__global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restrict__ work,
+__global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym S, const UpdWork* __restrict__ work,
                                                 const ComboDesc* __restrict__ combos, double* __restrict__ L,
                                                 double* __restrict__ scratch) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -184,13 +227,13 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
   const int32_t nrow = min(TM, m - R0);
   const int ncb = (w + 15) >> 4;
   if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
-  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += 256) smem[idx] = 0.0;
-  d4 acc[4][2];
+  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
+  // eight waves: wave wv owns target rows [16 wv, 16 wv + 16) and all 64 columns (4 accumulator tiles)
+  d4 acc[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  // this thread's fixed roles in the staging: A row t with k parity kpa; B column q with k phase kpb
+  for (int a = 0; a < 4; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+  // this thread's fixed roles in the staging: A row t with k phase kpa (of KA); B column q with k phase kpb (of KB)
+  constexpr int KA = UPD_THREADS / 128, KB = UPD_THREADS / 64;
   const int t = tid & 127, kpa = tid >> 7;
   const int q = tid & 63, kpb = tid >> 6;
   // per-buffer record of what this thread wrote (so that it can clear exactly that)
@@ -199,6 +242,7 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
   int64_t cn = cb;
   int k0n = 0;
   ComboDesc dn = combos[cn];
+  ComboDesc dnext = combos[min(cn + 1, ce - 1)];  // descriptor of the following combo, fetched one combo ahead
   int ipn = -1, jpn = -1;
   auto locate = [&]() {
     // tile position of this thread's descendant row / target column for combo dn
@@ -219,7 +263,7 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
     }
     if (q < dn.nq) jpn = (dn.jp0 >= 0) ? dn.jp0 + q : S.sn_rows[dn.rowoff + dn.p0 + q] - c0;
   };
-  double ra[KC / 2], rb[KC / 4];
+  double ra[KC / KA], rb[KC / KB];
   int kcn = 0;
   auto prefetch = [&]() {
     kcn = min(KC, dn.wd - k0n);
@@ -227,29 +271,29 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
     const int64_t md = dn.md;
     if (ABL == 2) {
 #pragma unroll
-      for (int i = 0; i < KC / 2; ++i) ra[i] = 1.0e-3;
+      for (int i = 0; i < KC / KA; ++i) ra[i] = 1.0e-3;
 #pragma unroll
-      for (int i = 0; i < KC / 4; ++i) rb[i] = 1.0e-3;
+      for (int i = 0; i < KC / KB; ++i) rb[i] = 1.0e-3;
       return;
     }
     if (ipn >= 0) {
       const double* pa = Pd + (int64_t)kpa * md + dn.ta + t;
       if (kcn == KC) {
 #pragma unroll
-        for (int i = 0; i < KC / 2; ++i) ra[i] = pa[(int64_t)(2 * i) * md];
+        for (int i = 0; i < KC / KA; ++i) ra[i] = pa[(int64_t)(KA * i) * md];
       } else {
 #pragma unroll
-        for (int i = 0; i < KC / 2; ++i) ra[i] = (kpa + 2 * i < kcn) ? pa[(int64_t)(2 * i) * md] : 0.0;
+        for (int i = 0; i < KC / KA; ++i) ra[i] = (kpa + KA * i < kcn) ? pa[(int64_t)(KA * i) * md] : 0.0;
       }
     }
     if (jpn >= 0) {
       const double* pb = Pd + (int64_t)kpb * md + dn.p0 + q;
       if (kcn == KC) {
 #pragma unroll
-        for (int i = 0; i < KC / 4; ++i) rb[i] = pb[(int64_t)(4 * i) * md];
+        for (int i = 0; i < KC / KB; ++i) rb[i] = pb[(int64_t)(KB * i) * md];
       } else {
 #pragma unroll
-        for (int i = 0; i < KC / 4; ++i) rb[i] = (kpb + 4 * i < kcn) ? pb[(int64_t)(4 * i) * md] : 0.0;
+        for (int i = 0; i < KC / KB; ++i) rb[i] = (kpb + KB * i < kcn) ? pb[(int64_t)(KB * i) * md] : 0.0;
       }
     }
   };
@@ -267,15 +311,15 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
     if (!same) {
       if (w_ip[b] >= 0) {
 #pragma unroll
-        for (int i = 0; i < KC / 2; ++i) {
-          const int k = kpa + 2 * i;
+        for (int i = 0; i < KC / KA; ++i) {
+          const int k = kpa + KA * i;
           if (k < w_kc[b]) As[k * LDA + w_ip[b]] = 0.0;
         }
       }
       if (w_jp[b] >= 0) {
 #pragma unroll
-        for (int i = 0; i < KC / 4; ++i) {
-          const int k = kpb + 4 * i;
+        for (int i = 0; i < KC / KB; ++i) {
+          const int k = kpb + KB * i;
           if (k < w_kc[b]) Bs[k * LDB + w_jp[b]] = 0.0;
         }
       }
@@ -285,22 +329,22 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
       double* wa = As + kpa * LDA + ipn;
       if (kcn == KC) {
 #pragma unroll
-        for (int i = 0; i < KC / 2; ++i) wa[2 * i * LDA] = ra[i];
+        for (int i = 0; i < KC / KA; ++i) wa[KA * i * LDA] = ra[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < KC / 2; ++i)
-          if (kpa + 2 * i < kcn) wa[2 * i * LDA] = ra[i];
+        for (int i = 0; i < KC / KA; ++i)
+          if (kpa + KA * i < kcn) wa[KA * i * LDA] = ra[i];
       }
     }
     if (jpn >= 0) {
       double* wb = Bs + kpb * LDB + jpn;
       if (kcn == KC) {
 #pragma unroll
-        for (int i = 0; i < KC / 4; ++i) wb[4 * i * LDB] = rb[i];
+        for (int i = 0; i < KC / KB; ++i) wb[KB * i * LDB] = rb[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < KC / 4; ++i)
-          if (kpb + 4 * i < kcn) wb[4 * i * LDB] = rb[i];
+        for (int i = 0; i < KC / KB; ++i)
+          if (kpb + KB * i < kcn) wb[KB * i * LDB] = rb[i];
       }
     }
     w_ip[b] = ipn;
@@ -319,7 +363,8 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
       ++cn;
       k0n = 0;
       if (cn >= ce) return false;
-      dn = combos[cn];
+      dn = dnext;
+      dnext = combos[min(cn + 1, ce - 1)];
       locate();
     }
     return true;
@@ -334,8 +379,8 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
   int buf = 0;
   while (true) {
     if (more) prefetch();  // global loads of the next chunk in flight during the MFMAs
-    if (ABL != 1 && 32 * wv < nrow)
-      tile_mma<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, ncb, lane, wv, acc);
+    if (ABL != 1 && 16 * wv < nrow)
+      tile_mma8<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, ncb, lane, wv, acc);
     if (!more) break;
     stage(buf ^ 1);
     kc4_cur = (kcn + 3) & ~3;
@@ -350,25 +395,21 @@ __global__ __launch_bounds__(256) void k_update(DevSym S, const UpdWork* __restr
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * jb + lr + 4 * r;
-          const int i = 32 * wv + 16 * ib + li;
-          if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][ib][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 16 * wv + li;
+        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][r];
+      }
   } else {
     double* Q = scratch + (int64_t)wk.slot * (TM * NB);
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * jb + lr + 4 * r;
-          const int i = 32 * wv + 16 * ib + li;
-          Q[j * TM + i] = acc[jb][ib][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 16 * wv + li;
+        Q[j * TM + i] = acc[jb][r];
+      }
   }
 }
 
@@ -475,22 +516,26 @@ __global__ __launch_bounds__(128) void k_reduce(DevSym S, const int32_t* __restr
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                double* __restrict__ invD, double* __restrict__ logd,
                                                int32_t* __restrict__ status) {
+  // One LDS array holds both triangles: T[i][k], i >= k is L; the inverse X (lower triangular) lives
+  // transposed in the strict upper part, X(r,c) = T[c][r] for r > c, with its diagonal in xd[].  34 KB, so a
+  // potrf workgroup fits on a CU next to two update workgroups (look-ahead keeps those resident).
   constexpr int LD = NB + 1;
-  __shared__ double Ls[NB * LD];
-  __shared__ double Xs[NB * LD];
+  __shared__ double T[NB * LD];
+  __shared__ double xd[NB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t s = fronts[blockIdx.x];
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   double* P = L + S.sn_loff[s];
   const int nb = (w + 15) >> 4, W = nb << 4;  // padded with an identity block
+#define XINV(r, c) ((r) > (c) ? T[(c) * LD + (r)] : ((r) == (c) ? xd[(r)] : 0.0))
   for (int idx = tid; idx < W * W; idx += 256) {
     const int k = idx / W, i = idx - k * W;
     double v = (i == k) ? 1.0 : 0.0;
     if (i < w && k < w) v = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
-    Ls[i * LD + k] = v;
-    Xs[i * LD + k] = 0.0;
+    T[i * LD + k] = v;
   }
+  if (tid < NB) xd[tid] = 1.0;
   __syncthreads();
   for (int kb = 0; kb < nb; ++kb) {
     const int o = kb << 4;
@@ -499,7 +544,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       const int r = lane & 15;
       double a[16], x[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = Ls[(o + r) * LD + o + c];
+      for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? T[(o + r) * LD + o + c] : 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double v = a[j];
@@ -525,9 +570,10 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          Ls[(o + r) * LD + o + c] = a[c];
-          Xs[(o + c) * LD + o + r] = x[c];
+          if (c <= r) T[(o + r) * LD + o + c] = a[c];        // L(o+r, o+c)
+          if (c > r) T[(o + r) * LD + o + c] = x[c];         // X(o+c, o+r), c > r, stored transposed
         }
+        xd[o + r] = x[r];
       }
     }
     __syncthreads();
@@ -541,8 +587,8 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
         tmp[q] = 0.0;
         if (idx < nrem * 16) {
           const int i = o + 16 + (idx >> 4), c = idx & 15;
-          double sum = 0.0;
-          for (int k = 0; k <= c; ++k) sum += Ls[i * LD + o + k] * Xs[(o + c) * LD + o + k];
+          double sum = T[i * LD + o + c] * xd[o + c];
+          for (int k = 0; k < c; ++k) sum += T[i * LD + o + k] * T[(o + k) * LD + o + c];
           tmp[q] = sum;
         }
       }
@@ -550,7 +596,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int idx = tid + 256 * q;
-        if (idx < nrem * 16) Ls[(o + 16 + (idx >> 4)) * LD + o + (idx & 15)] = tmp[q];
+        if (idx < nrem * 16) T[(o + 16 + (idx >> 4)) * LD + o + (idx & 15)] = tmp[q];
       }
       __syncthreads();
       // ---- trailing update (lower part): A[i][k'] -= sum_c B[i][c] B[k'][c]
@@ -560,8 +606,8 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
           const int i = o + 16 + ii, k2 = o + 16 + kk;
           double sum = 0.0;
 #pragma unroll
-          for (int c = 0; c < 16; ++c) sum += Ls[i * LD + o + c] * Ls[k2 * LD + o + c];
-          Ls[i * LD + k2] -= sum;
+          for (int c = 0; c < 16; ++c) sum += T[i * LD + o + c] * T[k2 * LD + o + c];
+          T[i * LD + k2] -= sum;
         }
       }
       __syncthreads();
@@ -578,8 +624,10 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       if (idx < nblk * 256) {
         const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
         const int i0 = (blk + d) << 4, j0 = blk << 4;
-        double sum = 0.0;
-        for (int kk = j0; kk < i0; ++kk) sum += Ls[(i0 + rr) * LD + kk] * Xs[kk * LD + j0 + cc];
+        const int col = j0 + cc;
+        // X(kk, col) is zero for kk < col
+        double sum = T[(i0 + rr) * LD + col] * xd[col];
+        for (int kk = col + 1; kk < i0; ++kk) sum += T[(i0 + rr) * LD + kk] * T[col * LD + kk];
         tmp[q] = sum;
       }
     }
@@ -589,7 +637,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       const int idx = tid + 256 * q;
       if (idx < nblk * 256) {
         const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
-        Xs[(((blk + d) << 4) + rr) * LD + (blk << 4) + cc] = tmp[q];
+        T[((blk << 4) + cc) * LD + ((blk + d) << 4) + rr] = tmp[q];  // temp at X(i0+rr, j0+cc)
       }
     }
     __syncthreads();
@@ -600,9 +648,9 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       if (idx < nblk * 256) {
         const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
         const int i0 = (blk + d) << 4, j0 = blk << 4;
-        double sum = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) sum += Xs[(i0 + rr) * LD + i0 + kk] * Xs[(i0 + kk) * LD + j0 + cc];
+        // sum_kk X(i0+rr, i0+kk) * temp(i0+kk, j0+cc), X_ii lower triangular: kk <= rr
+        double sum = xd[i0 + rr] * T[(j0 + cc) * LD + i0 + rr];
+        for (int kk = 0; kk < rr; ++kk) sum += T[(i0 + kk) * LD + i0 + rr] * T[(j0 + cc) * LD + i0 + kk];
         tmp[q] = -sum;
       }
     }
@@ -612,22 +660,23 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       const int idx = tid + 256 * q;
       if (idx < nblk * 256) {
         const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
-        Xs[(((blk + d) << 4) + rr) * LD + (blk << 4) + cc] = tmp[q];
+        T[((blk << 4) + cc) * LD + ((blk + d) << 4) + rr] = tmp[q];
       }
     }
     __syncthreads();
   }
   if (tid == 64) {
     double sl = 0.0;
-    for (int j = 0; j < w; ++j) sl += log(Ls[j * LD + j]);
+    for (int j = 0; j < w; ++j) sl += log(T[j * LD + j]);
     logd[s] = sl;
   }
   double* I = invD + S.inv_off[s];
   for (int idx = tid; idx < w * w; idx += 256) {
     const int k = idx / w, i = idx - k * w;
-    P[(int64_t)k * m + i] = (i >= k) ? Ls[i * LD + k] : 0.0;
-    I[k * w + i] = Xs[i * LD + k];
+    P[(int64_t)k * m + i] = (i >= k) ? T[i * LD + k] : 0.0;
+    I[k * w + i] = XINV(i, k);
   }
+#undef XINV
 }
 
 // ------------------------------------------------------------------------------------------------
