@@ -52,8 +52,12 @@ struct Dev {
   hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
   std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
   hipEvent_t ev_asm = nullptr;
-  int32_t* d_tile_pslot = nullptr;
+  int32_t* d_tile_pslot = nullptr;   // late partial slabs of a tile (main stream)
   int32_t* d_tile_pnseg = nullptr;
+  int32_t* d_tile_pslot_e = nullptr; // early partial slabs of a tile (side stream)
+  int32_t* d_tile_pnseg_e = nullptr;
+  int32_t* d_red_tiles_e = nullptr;
+  std::vector<int64_t> red_ptr_e;
   double* scratch = nullptr;       // max slots per level * TM*NB doubles
   int32_t* d_red_tiles = nullptr;  // tiles that carry partial slabs, grouped by level
   // cell-wise path for small update pairs: set 0 = early (side stream), set 1 = late (main stream)
@@ -311,6 +315,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->d_combos = (ComboDesc*)dc;
     const int64_t ntiles = (int64_t)S.tile_front.size();
     std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
+    std::vector<int32_t> pslot_e(pslot.size(), 0), pnseg_e(pslot.size(), 0), red_tiles_e;
+    D->red_ptr_e.assign(S.nlevels + 1, 0);
     std::vector<UpdWork> work, work_early;
     D->work_ptr.assign(S.nlevels + 1, 0);
     D->early_ptr.assign(S.nlevels + 1, 0);
@@ -365,19 +371,26 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         const int64_t pe = ne >= 2 ? ne : 0, pl = nl >= 2 ? nl : 0;
         if (ne == 1) work_early[fe].slot = -1;
         if (nl == 1) work[fl].slot = -1;
-        if (pe + pl > 0) {
-          pslot[g] = (int32_t)slots;
-          pnseg[g] = (int32_t)(pe + pl);
-          red_tiles.push_back(g);
+        if (pe > 0) {
+          pslot_e[g] = (int32_t)slots;
+          pnseg_e[g] = (int32_t)pe;
+          red_tiles_e.push_back(g);
           for (int64_t k = 0; k < pe; ++k) work_early[fe + k].slot = (int32_t)(slots + k);
-          for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + pe + k);
-          slots += pe + pl;
+          slots += pe;
+        }
+        if (pl > 0) {
+          pslot[g] = (int32_t)slots;
+          pnseg[g] = (int32_t)pl;
+          red_tiles.push_back(g);
+          for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + k);
+          slots += pl;
         }
       }
       max_slots = std::max(max_slots, slots);
       D->work_ptr[l + 1] = (int64_t)work.size();
       D->early_ptr[l + 1] = (int64_t)work_early.size();
       D->red_ptr[l + 1] = (int64_t)red_tiles.size();
+      D->red_ptr_e[l + 1] = (int64_t)red_tiles_e.size();
     }
     D->max_slots = std::max<int64_t>(max_slots, 1);
     if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
@@ -386,6 +399,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if ((st = upload(sym, D, work_early, &dwe)) != SCILMM_OK) return st;
       D->d_work_early = (UpdWork*)dwe;
     }
+    if (red_tiles_e.empty()) red_tiles_e.push_back(0);
+    if ((st = upload(sym, D, red_tiles_e, &tmp)) != SCILMM_OK) return st;
+    D->d_red_tiles_e = (int32_t*)tmp;
+    if ((st = upload(sym, D, pslot_e, &tmp)) != SCILMM_OK) return st;
+    D->d_tile_pslot_e = (int32_t*)tmp;
+    if ((st = upload(sym, D, pnseg_e, &tmp)) != SCILMM_OK) return st;
+    D->d_tile_pnseg_e = (int32_t*)tmp;
     if (red_tiles.empty()) red_tiles.push_back(0);
     if ((st = upload(sym, D, red_tiles, &tmp)) != SCILMM_OK) return st;
     D->d_red_tiles = (int32_t*)tmp;
@@ -409,12 +429,16 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
 int set_attrs(scilmm_symbolic* sym, Dev* D) {
   if (D->attrs_set) return SCILMM_OK;
   const int big = 150 * 1024;
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -547,6 +571,15 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)(l & 1) * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
+    {
+      // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
+      const int64_t q0 = D->red_ptr_e[l], q1 = D->red_ptr_e[l + 1];
+      if (q1 > q0) {
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)(16 * (q1 - q0))), dim3(128), 0, sd, D->v, D->d_red_tiles_e + q0,
+                           D->d_tile_pslot_e, D->d_tile_pnseg_e, (const double*)(D->scratch + (size_t)(l & 1) * half), fac->L);
+        launches++;
+      }
+    }
     launch_cells(sd, 0, l);  // early cells: same stream, after the early MFMA update of the same panels
     HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
     return SCILMM_OK;
@@ -665,20 +698,36 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     const int rp = rp_of(rc), ldy = ldy_of(rp);
     const int64_t tot = (int64_t)S.n * rp;
     const unsigned pb = (unsigned)((tot + 255) / 256);
-    const size_t sm_fwd = sizeof(double) * (size_t)(NB * LDB + NB * ldy + KC * LDA);
+    const size_t sm_fwd = sizeof(double) * (size_t)(NB * ldy + KC * LDA);
     const size_t sm_diag = sizeof(double) * (size_t)(NB * LDB + NB * ldy);
     const size_t sm_push = sizeof(double) * (size_t)(NB * LDP + 32 * ldy);
     if (mode == 0) {
       hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dB, D->W);
       for (int32_t l = 0; l < S.nlevels; ++l) {
         const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
-        if (t1 == t0) continue;
+        const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
+        if (f1 == f0) continue;
+        // x_s = invL_s * W[c0:c1] -> X rows c0..c1 (final), then push to the rows below
         if (mf)
-          hipLaunchKernelGGL((k_fwd<true, 0>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
-                             fac->L, fac->invD, (const double*)D->W, D->W, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_diag_solve<true, false>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
+                             D->d_level_fronts + f0, fac->invD, (const double*)D->W, D->X, rp, ldy);
         else
-          hipLaunchKernelGGL((k_fwd<false, 0>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
-                             fac->L, fac->invD, (const double*)D->W, D->W, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_diag_solve<false, false>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
+                             D->d_level_fronts + f0, fac->invD, (const double*)D->W, D->X, rp, ldy);
+        if (t1 == t0) continue;
+        const bool atomic = (f1 - f0) > 1;
+        if (mf && atomic)
+          hipLaunchKernelGGL((k_fwd<true, 0, true>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp, ldy);
+        else if (mf)
+          hipLaunchKernelGGL((k_fwd<true, 0, false>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp, ldy);
+        else if (atomic)
+          hipLaunchKernelGGL((k_fwd<false, 0, true>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp, ldy);
+        else
+          hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp, ldy);
       }
       if (!mid_recorded) {
         HIPCHK(hipEventRecord(D->ev[4], st));
@@ -689,11 +738,11 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         const int64_t p0 = S.level_pair_ptr[l], p1 = S.level_pair_ptr[l + 1];
         if (f1 > f0) {
           if (mf)
-            hipLaunchKernelGGL(k_bwd_diag<true>, dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v, D->d_level_fronts + f0,
-                               fac->invD, D->X, rp, ldy);
+            hipLaunchKernelGGL((k_diag_solve<true, true>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
+                               D->d_level_fronts + f0, fac->invD, (const double*)D->X, D->X, rp, ldy);
           else
-            hipLaunchKernelGGL(k_bwd_diag<false>, dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v, D->d_level_fronts + f0,
-                               fac->invD, D->X, rp, ldy);
+            hipLaunchKernelGGL((k_diag_solve<false, true>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
+                               D->d_level_fronts + f0, fac->invD, (const double*)D->X, D->X, rp, ldy);
         }
         if (p1 > p0) {
           if (mf)
@@ -711,11 +760,11 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
       HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, st));
       if (ntiles_all > 0) {
         if (mf)
-          hipLaunchKernelGGL((k_fwd<true, 1>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
-                             fac->invD, (const double*)D->W, D->X, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<true, 1, true>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
+                             (const double*)D->W, D->X, rp, ldy);
         else
-          hipLaunchKernelGGL((k_fwd<false, 1>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
-                             fac->invD, (const double*)D->W, D->X, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<false, 1, true>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
+                             (const double*)D->W, D->X, rp, ldy);
       }
       hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
     }

@@ -781,17 +781,68 @@ __device__ __forceinline__ void rhs_mma(const double* __restrict__ A_lds, int ld
   }
 }
 
-// Forward sweep of one level (push form).  Workgroup = (front s, 128-row tile):
-//   x_s = invL_s * W[c0:c1, :]            (every tile recomputes it; tile 0 publishes it to Xout)
-//   W[rows below] -= L21[tile rows, :] * x_s   through fp64 hardware atomics (rows of higher levels).
-// MODE 0: forward solve.  MODE 1: multiply (Z += L[:, s] * R_s, including the diagonal block).
-template <bool MFMA, int MODE>
-__global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
-                                             const double* __restrict__ invD, const double* Yin, double* W,
-                                             double* Xout, int32_t rp, int32_t ldy) {
+// Diagonal-block step of both sweeps, one workgroup per front of the level:
+//   TRANS = false:  Xout[c0:c1] = invL_s   * Yin[c0:c1]     (forward)
+//   TRANS = true :  Xout[c0:c1] = invL_s^T * Yin[c0:c1]     (backward, in place)
+// invL is triangular, so row block jb only needs k < 16 (jb+1) (forward) or k >= 16 jb (backward).
+template <bool MFMA, bool TRANS>
+__global__ __launch_bounds__(256) void k_diag_solve(DevSym S, const int32_t* __restrict__ fronts,
+                                                    const double* __restrict__ invD, const double* Yin, double* Xout,
+                                                    int32_t rp, int32_t ldy) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Is = smem;                 // [NB][LDB]   invL as Aop source: Is[k*LDB + j] = invL[j][k]
-  double* Ys = Is + NB * LDB;        // [NB][ldy]   y then x
+  double* Is = smem;           // Is[k*LDB + j] = op(invL)[j][k]
+  double* Ys = Is + NB * LDB;  // [NB][ldy]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t s = fronts[blockIdx.x];
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int ncn = rp >> 4;
+  const int w4 = (w + 3) & ~3;
+  const double* I = invD + S.inv_off[s];
+  {
+    const int c = tid & 127;
+    for (int k = tid >> 7; k < w4; k += 2) {
+      const double* src = Yin + (int64_t)(c0 + k) * rp;
+      if (c < ldy) Ys[k * ldy + c] = (k < w && c < rp) ? src[c] : 0.0;
+      if (c + 128 < ldy) Ys[k * ldy + c + 128] = 0.0;
+    }
+    const int j = tid & 63;
+    for (int k = tid >> 6; k < w4; k += 4) {
+      double v = 0.0;
+      if (k < w && j < w) v = TRANS ? I[j * w + k] : I[k * w + j];
+      Is[k * LDB + j] = v;
+      if (j < LDB - 64) Is[k * LDB + 64 + j] = 0.0;
+    }
+  }
+  __syncthreads();
+  d4 xa[RPMAX / 16];
+#pragma unroll
+  for (int cn = 0; cn < RPMAX / 16; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  if (16 * wv < w) {
+    const int kbeg = TRANS ? 16 * wv : 0;
+    const int kend = TRANS ? w4 : min(w4, 16 * (wv + 1));
+    rhs_mma<MFMA, RPMAX / 16>(Is + kbeg * LDB, LDB, 16 * wv, Ys + kbeg * ldy, ldy, kend - kbeg, ncn, lane, xa);
+    const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+    for (int cn = 0; cn < RPMAX / 16; ++cn)
+      if (cn < ncn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * wv + lr + 4 * r;
+          if (j < w) Xout[(int64_t)(c0 + j) * rp + 16 * cn + li] = xa[cn][r];
+        }
+  }
+}
+
+// Forward sweep of one level, push step.  Workgroup = (front s, 128-row tile beyond the diagonal block):
+//   W[rows of the tile] -= L21[tile rows, :] * x_s        with x_s = Xin[c0:c1] (from k_diag_solve).
+// ATOMIC: fronts of one level may share target rows -> fp64 hardware atomics; a level with a single front
+// (every level of a dense chain) uses plain read-modify-write.
+// MODE 0: forward solve.  MODE 1: multiply (Z += L[:, s] * R_s, including the diagonal block; always atomic).
+template <bool MFMA, int MODE, bool ATOMIC>
+__global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
+                                             const double* Xin, double* W, int32_t rp, int32_t ldy) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ys = smem;                 // [NB][ldy]   x_s (or R_s)
   double* As = Ys + NB * ldy;        // [KC][LDA]   panel chunk
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t g = tiles[blockIdx.x];
@@ -802,43 +853,18 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   const int32_t R0 = ti * TM;
   const int32_t nrow = min(TM, m - R0);
-  if (MODE == 0 && ti > 0 && R0 + nrow <= w) return;
+  if (MODE == 0 && R0 + nrow <= w) return;
   const int ncn = rp >> 4;
   const int w4 = (w + 3) & ~3;
   const double* P = L + S.sn_loff[s];
-  // stage y_s (and invL for the solve)
-  for (int idx = tid; idx < w4 * ldy; idx += 256) {
-    const int k = idx / ldy, c = idx - k * ldy;
-    Ys[idx] = (k < w && c < rp) ? Yin[(int64_t)(c0 + k) * rp + c] : 0.0;
-  }
-  if (MODE == 0) {
-    const double* I = invD + S.inv_off[s];
-    for (int idx = tid; idx < w4 * LDB; idx += 256) {
-      const int k = idx / LDB, j = idx - k * LDB;
-      Is[idx] = (k < w && j < w) ? I[k * w + j] : 0.0;
-    }
-    __syncthreads();
-    // x = invL * y : wave wv owns rows j in [16 wv, 16 wv + 16)
-    d4 xa[RPMAX / 16];
-#pragma unroll
-    for (int cn = 0; cn < RPMAX / 16; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (16 * wv < w) rhs_mma<MFMA, RPMAX / 16>(Is, LDB, 16 * wv, Ys, ldy, w4, ncn, lane, xa);
-    __syncthreads();
-    if (16 * wv < w) {
-      const int li = lane & 15, lr = lane >> 4;
-#pragma unroll
-      for (int cn = 0; cn < RPMAX / 16; ++cn)
-        if (cn < ncn)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * wv + lr + 4 * r;
-            Ys[j * ldy + 16 * cn + li] = (j < w) ? xa[cn][r] : 0.0;
-            if (ti == 0 && j < w) Xout[(int64_t)(c0 + j) * rp + 16 * cn + li] = xa[cn][r];
-          }
+  {
+    const int c = tid & 127;
+    for (int k = tid >> 7; k < w4; k += 2) {
+      const double* src = Xin + (int64_t)(c0 + k) * rp;
+      if (c < ldy) Ys[k * ldy + c] = (k < w && c < rp) ? src[c] : 0.0;
+      if (c + 128 < ldy) Ys[k * ldy + c + 128] = 0.0;
     }
   }
-  __syncthreads();
-  if (MODE == 0 && R0 + nrow <= w) return;
   // acc[i][c] = sum_k P[R0+i][k] * x[k][c]; wave wv owns rows [32 wv, 32 wv + 32)
   d4 a0[RPMAX / 16], a1[RPMAX / 16];
 #pragma unroll
@@ -867,57 +893,17 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
     if (cn < ncn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int i = 32 * wv + lr + 4 * r;
-        if (i < nrow && (MODE == 1 || R0 + i >= w)) {
-          double v = a0[cn][r];
-          unsafeAtomicAdd(&W[(int64_t)rs[R0 + i] * rp + 16 * cn + li], MODE == 0 ? -v : v);
-        }
-        i += 16;
-        if (i < nrow && (MODE == 1 || R0 + i >= w)) {
-          double v = a1[cn][r];
-          unsafeAtomicAdd(&W[(int64_t)rs[R0 + i] * rp + 16 * cn + li], MODE == 0 ? -v : v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = 32 * wv + 16 * h + lr + 4 * r;
+          if (i < nrow && (MODE == 1 || R0 + i >= w)) {
+            const double v = h == 0 ? a0[cn][r] : a1[cn][r];
+            double* dst = &W[(int64_t)rs[R0 + i] * rp + 16 * cn + li];
+            if (ATOMIC) unsafeAtomicAdd(dst, MODE == 0 ? -v : v);
+            else *dst += (MODE == 0 ? -v : v);
+          }
         }
       }
-}
-
-// Backward sweep, step (a): x_s = invL_s^T * y_s in place on X rows c0..c1 (one workgroup per front).
-template <bool MFMA>
-__global__ __launch_bounds__(256) void k_bwd_diag(DevSym S, const int32_t* __restrict__ fronts,
-                                                  const double* __restrict__ invD, double* __restrict__ X, int32_t rp,
-                                                  int32_t ldy) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Is = smem;           // Is[k*LDB + j] = invL[k][j]  (Aop[j][k] = invL^T[j][k])
-  double* Ys = Is + NB * LDB;  // [NB][ldy]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int32_t s = fronts[blockIdx.x];
-  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
-  const int ncn = rp >> 4;
-  const int w4 = (w + 3) & ~3;
-  const double* I = invD + S.inv_off[s];
-  for (int idx = tid; idx < w4 * ldy; idx += 256) {
-    const int k = idx / ldy, c = idx - k * ldy;
-    Ys[idx] = (k < w && c < rp) ? X[(int64_t)(c0 + k) * rp + c] : 0.0;
-  }
-  for (int idx = tid; idx < w4 * LDB; idx += 256) {
-    const int k = idx / LDB, j = idx - k * LDB;
-    Is[idx] = (k < w && j < w) ? I[j * w + k] : 0.0;  // element (k, j) of the column-major inverse
-  }
-  __syncthreads();
-  d4 xa[RPMAX / 16];
-#pragma unroll
-  for (int cn = 0; cn < RPMAX / 16; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
-  if (16 * wv < w) {
-    rhs_mma<MFMA, RPMAX / 16>(Is, LDB, 16 * wv, Ys, ldy, w4, ncn, lane, xa);
-    const int li = lane & 15, lr = lane >> 4;
-#pragma unroll
-    for (int cn = 0; cn < RPMAX / 16; ++cn)
-      if (cn < ncn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * wv + lr + 4 * r;
-          if (j < w) X[(int64_t)(c0 + j) * rp + 16 * cn + li] = xa[cn][r];
-        }
-  }
 }
 
 // Backward sweep, step (b): for every update pair (target s in this level, descendant d)
