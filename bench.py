@@ -155,6 +155,10 @@ def main():
 
     if rank == 0:
         K = args.steps
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_v4_traffic.json")
+        if args.workload == "100k" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch"]  # PMC pass taken offline (see the file), per launch
         upd_s = prof["update_ms"] / 1e3
         n_upd = max(prof["n_update_launches"], 1)
         ach = info.update_flops * K / max(upd_s, 1e-12) / 1e12
@@ -179,7 +183,8 @@ def main():
                        "symbolic_s": t_sym, "generate_s": t_gen, "logdet": logdet_total, "solve_residual": resid},
             "roofline": {"bound": "mfma", "kernel": "k_update<true> (fp64 MFMA supernodal update)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "measured_sustained_mfma_f64_tflops": 49.4,
                          "flops_per_launch": info.update_flops / n_upd * K,
                          "avg_launch_ms": prof["update_ms"] / n_upd,
                          "launches": int(n_upd)},
