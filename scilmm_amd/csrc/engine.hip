@@ -429,18 +429,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
 int set_attrs(scilmm_symbolic* sym, Dev* D) {
   if (D->attrs_set) return SCILMM_OK;
   const int big = 150 * 1024;
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_diag_solve<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_bwd_push<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -695,12 +683,10 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
   bool mid_recorded = false;
   for (int32_t cbeg = 0; cbeg < r; cbeg += RPMAX) {
     const int rc = std::min<int>(RPMAX, r - cbeg);
-    const int rp = rp_of(rc), ldy = ldy_of(rp);
+    const int rp = rp_of(rc);
+    const unsigned gy = (unsigned)((rp + CW - 1) / CW);
     const int64_t tot = (int64_t)S.n * rp;
     const unsigned pb = (unsigned)((tot + 255) / 256);
-    const size_t sm_fwd = sizeof(double) * (size_t)(NB * ldy + KC * LDA);
-    const size_t sm_diag = sizeof(double) * (size_t)(NB * LDB + NB * ldy);
-    const size_t sm_push = sizeof(double) * (size_t)(NB * LDP + 32 * ldy);
     if (mode == 0) {
       hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dB, D->W);
       for (int32_t l = 0; l < S.nlevels; ++l) {
@@ -709,25 +695,25 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         if (f1 == f0) continue;
         // x_s = invL_s * W[c0:c1] -> X rows c0..c1 (final), then push to the rows below
         if (mf)
-          hipLaunchKernelGGL((k_diag_solve<true, false>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
-                             D->d_level_fronts + f0, fac->invD, (const double*)D->W, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_diag_solve<true, false>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v,
+                             D->d_level_fronts + f0, fac->invD, (const double*)D->W, D->X, rp);
         else
-          hipLaunchKernelGGL((k_diag_solve<false, false>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
-                             D->d_level_fronts + f0, fac->invD, (const double*)D->W, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_diag_solve<false, false>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v,
+                             D->d_level_fronts + f0, fac->invD, (const double*)D->W, D->X, rp);
         if (t1 == t0) continue;
         const bool atomic = (f1 - f0) > 1;
         if (mf && atomic)
-          hipLaunchKernelGGL((k_fwd<true, 0, true>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
-                             fac->L, (const double*)D->X, D->W, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<true, 0, true>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp);
         else if (mf)
-          hipLaunchKernelGGL((k_fwd<true, 0, false>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
-                             fac->L, (const double*)D->X, D->W, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<true, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp);
         else if (atomic)
-          hipLaunchKernelGGL((k_fwd<false, 0, true>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
-                             fac->L, (const double*)D->X, D->W, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<false, 0, true>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp);
         else
-          hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - t0)), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
-                             fac->L, (const double*)D->X, D->W, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+                             fac->L, (const double*)D->X, D->W, rp);
       }
       if (!mid_recorded) {
         HIPCHK(hipEventRecord(D->ev[4], st));
@@ -738,19 +724,19 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         const int64_t p0 = S.level_pair_ptr[l], p1 = S.level_pair_ptr[l + 1];
         if (f1 > f0) {
           if (mf)
-            hipLaunchKernelGGL((k_diag_solve<true, true>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
-                               D->d_level_fronts + f0, fac->invD, (const double*)D->X, D->X, rp, ldy);
+            hipLaunchKernelGGL((k_diag_solve<true, true>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v,
+                               D->d_level_fronts + f0, fac->invD, (const double*)D->X, D->X, rp);
           else
-            hipLaunchKernelGGL((k_diag_solve<false, true>), dim3((unsigned)(f1 - f0)), dim3(256), sm_diag, st, D->v,
-                               D->d_level_fronts + f0, fac->invD, (const double*)D->X, D->X, rp, ldy);
+            hipLaunchKernelGGL((k_diag_solve<false, true>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v,
+                               D->d_level_fronts + f0, fac->invD, (const double*)D->X, D->X, rp);
         }
         if (p1 > p0) {
           if (mf)
-            hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)(p1 - p0)), dim3(256), sm_push, st, D->v, D->d_level_pairs + p0,
-                               fac->L, D->X, rp, ldy);
+            hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
+                               fac->L, D->X, rp);
           else
-            hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)(p1 - p0)), dim3(256), sm_push, st, D->v, D->d_level_pairs + p0,
-                               fac->L, D->X, rp, ldy);
+            hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
+                               fac->L, D->X, rp);
         }
       }
       hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
@@ -760,11 +746,11 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
       HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, st));
       if (ntiles_all > 0) {
         if (mf)
-          hipLaunchKernelGGL((k_fwd<true, 1, true>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
-                             (const double*)D->W, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<true, 1, true>), dim3((unsigned)ntiles_all, gy), dim3(256), 0, st, D->v, D->d_level_tiles, fac->L,
+                             (const double*)D->W, D->X, rp);
         else
-          hipLaunchKernelGGL((k_fwd<false, 1, true>), dim3((unsigned)ntiles_all), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
-                             (const double*)D->W, D->X, rp, ldy);
+          hipLaunchKernelGGL((k_fwd<false, 1, true>), dim3((unsigned)ntiles_all, gy), dim3(256), 0, st, D->v, D->d_level_tiles, fac->L,
+                             (const double*)D->W, D->X, rp);
       }
       hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
     }

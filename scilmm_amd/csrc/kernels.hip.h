@@ -781,70 +781,81 @@ __device__ __forceinline__ void rhs_mma(const double* __restrict__ A_lds, int ld
   }
 }
 
-// Diagonal-block step of both sweeps, one workgroup per front of the level:
+// Right-hand-side kernels work on a window of CW = 32 columns selected by blockIdx.y (gridDim.y =
+// ceil(rp / CW)): four times the workgroups per level, a quarter of the MFMA chain and of the staging per
+// workgroup, 24 KB LDS images.  Global RHS rows keep the full stride rp.
+#ifndef SCILMM_CW
+#define SCILMM_CW 32
+#endif
+constexpr int CW = SCILMM_CW;  // RHS columns per workgroup
+constexpr int LDW = 48;        // LDS leading dimension of [k][c] images (== 16 mod 32, >= CW)
+constexpr int NCT = CW / 16;   // 16-column MFMA tiles per window
+
+// Diagonal-block step of both sweeps, one workgroup per (front of the level, column window):
 //   TRANS = false:  Xout[c0:c1] = invL_s   * Yin[c0:c1]     (forward)
 //   TRANS = true :  Xout[c0:c1] = invL_s^T * Yin[c0:c1]     (backward, in place)
 // invL is triangular, so row block jb only needs k < 16 (jb+1) (forward) or k >= 16 jb (backward).
 template <bool MFMA, bool TRANS>
 __global__ __launch_bounds__(256) void k_diag_solve(DevSym S, const int32_t* __restrict__ fronts,
                                                     const double* __restrict__ invD, const double* Yin, double* Xout,
-                                                    int32_t rp, int32_t ldy) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Is = smem;           // Is[k*LDB + j] = op(invL)[j][k]
-  double* Ys = Is + NB * LDB;  // [NB][ldy]
+                                                    int32_t rp) {
+  __shared__ __attribute__((aligned(16))) double Is[NB * LDB];  // Is[k*LDB + j] = op(invL)[j][k]
+  __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c_lo = blockIdx.y * CW;
+  const int rpl = min(CW, rp - c_lo);
+  if (rpl <= 0) return;
   const int32_t s = fronts[blockIdx.x];
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
-  const int ncn = rp >> 4;
+  const int ncn = rpl >> 4;
   const int w4 = (w + 3) & ~3;
   const double* I = invD + S.inv_off[s];
   {
-    const int c = tid & 127;
-    for (int k = tid >> 7; k < w4; k += 2) {
-      const double* src = Yin + (int64_t)(c0 + k) * rp;
-      if (c < ldy) Ys[k * ldy + c] = (k < w && c < rp) ? src[c] : 0.0;
-      if (c + 128 < ldy) Ys[k * ldy + c + 128] = 0.0;
-    }
+    const int c = tid & 63;
+    if (c < LDW)
+      for (int k = tid >> 6; k < w4; k += 4)
+        Ys[k * LDW + c] = (k < w && c < rpl) ? Yin[(int64_t)(c0 + k) * rp + c_lo + c] : 0.0;
     const int j = tid & 63;
     for (int k = tid >> 6; k < w4; k += 4) {
       double v = 0.0;
       if (k < w && j < w) v = TRANS ? I[j * w + k] : I[k * w + j];
       Is[k * LDB + j] = v;
-      if (j < LDB - 64) Is[k * LDB + 64 + j] = 0.0;
     }
   }
   __syncthreads();
-  d4 xa[RPMAX / 16];
+  d4 xa[NCT];
 #pragma unroll
-  for (int cn = 0; cn < RPMAX / 16; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int cn = 0; cn < NCT; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
   if (16 * wv < w) {
     const int kbeg = TRANS ? 16 * wv : 0;
     const int kend = TRANS ? w4 : min(w4, 16 * (wv + 1));
-    rhs_mma<MFMA, RPMAX / 16>(Is + kbeg * LDB, LDB, 16 * wv, Ys + kbeg * ldy, ldy, kend - kbeg, ncn, lane, xa);
+    rhs_mma<MFMA, NCT>(Is + kbeg * LDB, LDB, 16 * wv, Ys + kbeg * LDW, LDW, kend - kbeg, ncn, lane, xa);
     const int li = lane & 15, lr = lane >> 4;
 #pragma unroll
-    for (int cn = 0; cn < RPMAX / 16; ++cn)
+    for (int cn = 0; cn < NCT; ++cn)
       if (cn < ncn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * wv + lr + 4 * r;
-          if (j < w) Xout[(int64_t)(c0 + j) * rp + 16 * cn + li] = xa[cn][r];
+          if (j < w) Xout[(int64_t)(c0 + j) * rp + c_lo + 16 * cn + li] = xa[cn][r];
         }
   }
 }
 
-// Forward sweep of one level, push step.  Workgroup = (front s, 128-row tile beyond the diagonal block):
+// Forward sweep of one level, push step.  Workgroup = (front s, 128-row tile, column window):
 //   W[rows of the tile] -= L21[tile rows, :] * x_s        with x_s = Xin[c0:c1] (from k_diag_solve).
 // ATOMIC: fronts of one level may share target rows -> fp64 hardware atomics; a level with a single front
 // (every level of a dense chain) uses plain read-modify-write.
 // MODE 0: forward solve.  MODE 1: multiply (Z += L[:, s] * R_s, including the diagonal block; always atomic).
 template <bool MFMA, int MODE, bool ATOMIC>
 __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
-                                             const double* Xin, double* W, int32_t rp, int32_t ldy) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Ys = smem;                 // [NB][ldy]   x_s (or R_s)
-  double* As = Ys + NB * ldy;        // [KC][LDA]   panel chunk
+                                             const double* Xin, double* W, int32_t rp) {
+  __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // x_s (or R_s), [k][c]
+  __shared__ __attribute__((aligned(16))) double As[KC * LDA];  // panel chunk, [k][row]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c_lo = blockIdx.y * CW;
+  const int rpl = min(CW, rp - c_lo);
+  if (rpl <= 0) return;
   const int32_t g = tiles[blockIdx.x];
   const int32_t s = S.tile_front[g];
   const int32_t ti = (int32_t)(g - S.tile_base[s]);
@@ -854,21 +865,19 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
   const int32_t R0 = ti * TM;
   const int32_t nrow = min(TM, m - R0);
   if (MODE == 0 && R0 + nrow <= w) return;
-  const int ncn = rp >> 4;
+  const int ncn = rpl >> 4;
   const int w4 = (w + 3) & ~3;
   const double* P = L + S.sn_loff[s];
   {
-    const int c = tid & 127;
-    for (int k = tid >> 7; k < w4; k += 2) {
-      const double* src = Xin + (int64_t)(c0 + k) * rp;
-      if (c < ldy) Ys[k * ldy + c] = (k < w && c < rp) ? src[c] : 0.0;
-      if (c + 128 < ldy) Ys[k * ldy + c + 128] = 0.0;
-    }
+    const int c = tid & 63;
+    if (c < LDW)
+      for (int k = tid >> 6; k < w4; k += 4)
+        Ys[k * LDW + c] = (k < w && c < rpl) ? Xin[(int64_t)(c0 + k) * rp + c_lo + c] : 0.0;
   }
   // acc[i][c] = sum_k P[R0+i][k] * x[k][c]; wave wv owns rows [32 wv, 32 wv + 32)
-  d4 a0[RPMAX / 16], a1[RPMAX / 16];
+  d4 a0[NCT], a1[NCT];
 #pragma unroll
-  for (int cn = 0; cn < RPMAX / 16; ++cn) {
+  for (int cn = 0; cn < NCT; ++cn) {
     a0[cn] = (d4){0.0, 0.0, 0.0, 0.0};
     a1[cn] = (d4){0.0, 0.0, 0.0, 0.0};
   }
@@ -883,13 +892,13 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
     }
     __syncthreads();
     if (32 * wv < nrow) {
-      rhs_mma<MFMA, RPMAX / 16>(As, LDA, 32 * wv, Ys + k0 * ldy, ldy, kc4, ncn, lane, a0);
-      if (32 * wv + 16 < nrow) rhs_mma<MFMA, RPMAX / 16>(As, LDA, 32 * wv + 16, Ys + k0 * ldy, ldy, kc4, ncn, lane, a1);
+      rhs_mma<MFMA, NCT>(As, LDA, 32 * wv, Ys + k0 * LDW, LDW, kc4, ncn, lane, a0);
+      if (32 * wv + 16 < nrow) rhs_mma<MFMA, NCT>(As, LDA, 32 * wv + 16, Ys + k0 * LDW, LDW, kc4, ncn, lane, a1);
     }
   }
   const int li = lane & 15, lr = lane >> 4;
 #pragma unroll
-  for (int cn = 0; cn < RPMAX / 16; ++cn)
+  for (int cn = 0; cn < NCT; ++cn)
     if (cn < ncn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
           const int i = 32 * wv + 16 * h + lr + 4 * r;
           if (i < nrow && (MODE == 1 || R0 + i >= w)) {
             const double v = h == 0 ? a0[cn][r] : a1[cn][r];
-            double* dst = &W[(int64_t)rs[R0 + i] * rp + 16 * cn + li];
+            double* dst = &W[(int64_t)rs[R0 + i] * rp + c_lo + 16 * cn + li];
             if (ATOMIC) unsafeAtomicAdd(dst, MODE == 0 ? -v : v);
             else *dst += (MODE == 0 ? -v : v);
           }
@@ -912,22 +921,23 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
 // read-modify-write of X[cols of d] is exclusive: plain loads/stores, bitwise reproducible.
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __restrict__ pairs,
-                                                  const double* __restrict__ L, double* __restrict__ X, int32_t rp,
-                                                  int32_t ldy) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Ps = smem;             // [NB][LDP]  Ps[k*LDP + q] = L_d[p0+q0+q][k]
-  double* Xg = Ps + NB * LDP;    // [32][ldy]  gathered X rows
+                                                  const double* __restrict__ L, double* __restrict__ X, int32_t rp) {
+  __shared__ __attribute__((aligned(16))) double Ps[NB * LDP];  // Ps[k*LDP + q] = L_d[p0+q0+q][k]
+  __shared__ __attribute__((aligned(16))) double Xg[32 * LDW];  // gathered X rows, [q][c]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c_lo = blockIdx.y * CW;
+  const int rpl = min(CW, rp - c_lo);
+  if (rpl <= 0) return;
   const int32_t e = pairs[blockIdx.x];
   const int32_t d = S.upd_src[e], p0 = S.upd_p0[e], p1 = S.upd_p1[e];
   const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
   const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
   const int32_t cd = S.sn_start[d], wd = S.sn_start[d + 1] - cd;
   const double* Pd = L + S.sn_loff[d];
-  const int ncn = rp >> 4;
-  d4 acc[RPMAX / 16];
+  const int ncn = rpl >> 4;
+  d4 acc[NCT];
 #pragma unroll
-  for (int cn = 0; cn < RPMAX / 16; ++cn) acc[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int cn = 0; cn < NCT; ++cn) acc[cn] = (d4){0.0, 0.0, 0.0, 0.0};
   for (int32_t q0 = p0; q0 < p1; q0 += 32) {
     const int qn = min(32, p1 - q0);
     const int qn4 = (qn + 3) & ~3;
@@ -936,10 +946,10 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
       const int q = tid & 31;
       for (int k = tid >> 5; k < NB; k += 8)
         Ps[k * LDP + q] = (q < qn && k < wd) ? Pd[(int64_t)k * md + q0 + q] : 0.0;
-      for (int idx = tid; idx < qn4 * ldy; idx += 256) {
-        const int q2 = idx / ldy, c = idx - q2 * ldy;
-        Xg[idx] = (q2 < qn && c < rp) ? X[(int64_t)rd[q0 + q2] * rp + c] : 0.0;
-      }
+      const int c = tid & 63;
+      if (c < LDW)
+        for (int q2 = tid >> 6; q2 < qn4; q2 += 4)
+          Xg[q2 * LDW + c] = (q2 < qn && c < rpl) ? X[(int64_t)rd[q0 + q2] * rp + c_lo + c] : 0.0;
     }
     __syncthreads();
     if (16 * wv < wd) {
@@ -949,28 +959,28 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
         for (int q4 = 0; q4 < qn4; q4 += 4) {
           const double a = Ps[(16 * wv + li) * LDP + q4 + lk];
 #pragma unroll
-          for (int cn = 0; cn < RPMAX / 16; ++cn)
-            if (cn < ncn) acc[cn] = mfma_f64(a, Xg[(q4 + lk) * ldy + 16 * cn + li], acc[cn]);
+          for (int cn = 0; cn < NCT; ++cn)
+            if (cn < ncn) acc[cn] = mfma_f64(a, Xg[(q4 + lk) * LDW + 16 * cn + li], acc[cn]);
         }
       } else {
         for (int q = 0; q < qn4; ++q)
 #pragma unroll
-          for (int cn = 0; cn < RPMAX / 16; ++cn)
+          for (int cn = 0; cn < NCT; ++cn)
             if (cn < ncn)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc[cn][r] += Ps[(16 * wv + lk + 4 * r) * LDP + q] * Xg[q * ldy + 16 * cn + li];
+              for (int r = 0; r < 4; ++r) acc[cn][r] += Ps[(16 * wv + lk + 4 * r) * LDP + q] * Xg[q * LDW + 16 * cn + li];
       }
     }
   }
   if (16 * wv < wd) {
     const int li = lane & 15, lr = lane >> 4;
 #pragma unroll
-    for (int cn = 0; cn < RPMAX / 16; ++cn)
+    for (int cn = 0; cn < NCT; ++cn)
       if (cn < ncn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * wv + lr + 4 * r;
-          if (k < wd) X[(int64_t)(cd + k) * rp + 16 * cn + li] -= acc[cn][r];
+          if (k < wd) X[(int64_t)(cd + k) * rp + c_lo + 16 * cn + li] -= acc[cn][r];
         }
   }
 }

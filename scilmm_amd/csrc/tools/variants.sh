@@ -1,2 +1,2 @@
-for v in libscilmm_hip.so libscilmm_hip_kc8_w3.so libscilmm_hip_kc16_w3.so libscilmm_hip_kc8_w4.so; do for la in 1 0; do SCILMM_NO_LOOKAHEAD=$la SCILMM_HIP_LIB=$PWD/scilmm_amd/csrc/$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());c=d['config'];print('$v nolook=$la',{k:round(c[k],1) for k in ['factorize_ms','update_ms','reduce_cells_ms','potrf_ms','trsm_ms']}, c['solve_residual'])"; done; done
+for v in libscilmm_hip.so libscilmm_hip_cw16.so; do SCILMM_HIP_LIB=$PWD/scilmm_amd/csrc/$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());c=d['config'];print('$v',{k:round(c[k],1) for k in ['factorize_ms','solve_ms','solve_fwd_ms','solve_bwd_ms']}, c['solve_residual'])"; done
