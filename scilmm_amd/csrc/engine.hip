@@ -144,8 +144,29 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(hipStreamCreateWithPriority(&D->stream, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, lo));
-    HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
+    // SCILMM_RESERVE_CUS = r > 0: the look-ahead side streams are created with a CU mask that leaves r CUs per
+    // XCD-group free, so the main stream's single-workgroup kernels never queue behind resident update items.
+    const char* er = getenv("SCILMM_RESERVE_CUS");
+    const int reserve = er ? atoi(er) : 0;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    if (reserve > 0 && reserve < ncu) {
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      // keep every (ncu / reserve)-th CU out of the mask so the reserved CUs are spread over the XCDs
+      const int stride = std::max(1, ncu / reserve);
+      int kept_out = 0;
+      for (int c = 0; c < ncu; ++c) {
+        const bool out = (c % stride == stride - 1) && kept_out < reserve;
+        if (out) { kept_out++; continue; }
+        mask[c / 32] |= (1u << (c % 32));
+      }
+      HIPCHK(hipExtStreamCreateWithCUMask(&D->side, (uint32_t)mask.size(), mask.data()));
+      HIPCHK(hipExtStreamCreateWithCUMask(&D->side2, (uint32_t)mask.size(), mask.data()));
+    } else {
+      HIPCHK(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, lo));
+      HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
+    }
   }
   HIPCHK(hipEventCreateWithFlags(&D->ev_asm, hipEventDisableTiming));
   D->lev_ev.assign((size_t)2 * std::max(S.nlevels, 1), nullptr);
@@ -195,7 +216,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const int64_t nc = (int64_t)S.combo_pair.size();
     const int64_t ntiles0 = (int64_t)S.tile_front.size();
     const char* ecs = getenv("SCILMM_CELL_LIMIT");
-    const double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
+    const double cell_limit = ecs ? atof(ecs) : 1024.0;  // pairs with cells*width below this take the cell-wise path
     std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
     std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
     const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
