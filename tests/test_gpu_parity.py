@@ -162,3 +162,47 @@ def test_pedigree_denser_10k():
     B = rng.standard_normal((n, 103))
     assert rel_err(f(B), o(B)) < TOL
     assert rel_err(f.lmul(B), o.lmul(B)) < TOL
+
+
+def test_factorization_is_bitwise_reproducible():
+    """No float atomics in the factorization: the same inputs give the same bits (factor and log-det)."""
+    A, _ = small_pedigree(10000, 0.01, 0)
+    n = A.shape[0]
+    sym = _engine([A, sp.identity(n, format="csr")])
+    f = sym.factorize([0.4, 0.6])
+    ld1, L1 = f.logdet(), f.L()
+    f.refactorize([0.7, 0.2])
+    f.refactorize([0.4, 0.6])
+    ld2, L2 = f.logdet(), f.L()
+    assert ld1 == ld2
+    assert np.array_equal(L1.data, L2.data) and np.array_equal(L1.indices, L2.indices)
+
+
+def test_full_size_properties_100k():
+    """BASELINE config 2 (100k, sf 0.005) at full size through size-independent properties."""
+    from scilmm_amd.harness.pedigree import make_problem
+    mats, C, y = make_problem(100000, 0.005, seed=0)
+    A = mats[0]
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    sym = _engine([A, I])
+    s2 = [0.4, 0.6]
+    f = sym.factorize(s2)
+    V = (s2[0] * A + s2[1] * I).tocsr()
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((n, 5))
+    X = f(B)
+    assert rel_err(V @ X, B) < 1e-11                       # residual
+    assert rel_err(f(V @ B), B) < 1e-11                    # V^-1 (V b) = b
+    ld = f.logdet()
+    f2 = sym.factorize([2.0 * s2[0], 2.0 * s2[1]])
+    assert abs(f2.logdet() - (ld + n * np.log(2.0))) < 1e-9 * abs(ld)   # logdet(cV) = logdet V + n log c
+    R = rng.standard_normal((n, 4))
+    Z = f.lmul(R)
+    assert rel_err(Z.T @ f(Z), R.T @ R) < 1e-10            # Z' V^-1 Z = R'R  (Z = P^T L R)
+    U = f(B)
+    q = sym.quadforms(0, U)
+    assert rel_err(q, ((A @ U) * U).sum(axis=0)) < 1e-11   # fused SpMM + reduce
+    assert rel_err(sym.quadforms(1, U), (U * U).sum(axis=0)) < 1e-12
+    info = sym.info()
+    assert info.nnzL > 1e8 and info.flops > 1e12
