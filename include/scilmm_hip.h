@@ -116,6 +116,18 @@ int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
  * live roofline figure).  Off by default. */
 int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on);
 
+/* --- SURVEY section 8(f) rank 1 ("next"): pedigree -> IBD matrix, the producer of the hot path's input.
+ * Replaces Numerator.LD + create_numerator (scilmm/Matrices/Numerator.py:5-38) and, with count_only != 0,
+ * Relationship.count_IBD_nonzero (scilmm/Matrices/Relationship.py:38-61).  parents: n x 2 int32, -1 = unknown,
+ * individuals in topological order (parents first).  Host C++/OpenMP; no device needed. */
+typedef struct scilmm_ibd scilmm_ibd;
+int scilmm_ibd_build(int32_t n, const int32_t* parents, int32_t count_only, scilmm_ibd** out, int64_t* nnz);
+int scilmm_ibd_sizes(const scilmm_ibd* h, int64_t* nnz_A, int64_t* nnz_L);
+/* A: symmetric CSR (both triangles, sorted); L: ancestor-weight rows; D, F: length n.  NULL pointers are skipped. */
+int scilmm_ibd_export(const scilmm_ibd* h, int64_t* a_indptr, int32_t* a_indices, double* a_data, int64_t* l_indptr,
+                      int32_t* l_indices, double* l_data, double* D, double* F);
+void scilmm_ibd_free(scilmm_ibd* h);
+
 const char* scilmm_version(void);
 
 #ifdef __cplusplus

@@ -60,6 +60,7 @@ SYMBOLS = [
     "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
     "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
+    "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
 ]
 
 _lib = None
@@ -101,6 +102,11 @@ def lib():
     L.scilmm_last_timing.argtypes = [vp, P(Timing)]
     L.scilmm_set_profiling.argtypes = [vp, i32]
     L.scilmm_version.restype = C.c_char_p
+    L.scilmm_ibd_build.argtypes = [i32, vp, i32, P(vp), P(i64)]
+    L.scilmm_ibd_sizes.argtypes = [vp, P(i64), P(i64)]
+    L.scilmm_ibd_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.scilmm_ibd_free.argtypes = [vp]
+    L.scilmm_ibd_free.restype = None
     _lib = L
     return L
 
