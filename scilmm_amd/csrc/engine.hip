@@ -172,6 +172,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   D->lev_ev.assign((size_t)2 * std::max(S.nlevels, 1), nullptr);
   for (auto& e : D->lev_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : D->ev) HIPCHK(hipEventCreate(&e));
+  for (int32_t b = 0; b < S.nsuper; ++b)
+    if (S.sn_start[b + 1] - S.sn_start[b] > NB) {
+      sym->err = "symbolic analysis has supernode blocks wider than the kernels' block width (max_width > NB)";
+      return SCILMM_ERR_ARG;
+    }
   const char* nm = getenv("SCILMM_NO_MFMA");
   D->use_mfma = !(nm && nm[0] == '1');
   const char* ab = getenv("SCILMM_ABLATE");
@@ -247,6 +252,15 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         x.nq = S.upd_p1[e] - S.upd_p0[e];
         x.ip0 = S.combo_ip0[c];
         x.jp0 = S.upd_jp0[e];
+        {
+          // spans in target coordinates: rows and columns of a descendant are sorted, so first/last suffice
+          const int32_t* rdx = S.sn_rows.data() + x.rowoff;
+          const int32_t* lo0 = rs + R0;
+          x.ilo = (int32_t)(std::lower_bound(lo0, rs + tile_end, rdx[x.ta]) - lo0);
+          x.ihi = (int32_t)(std::lower_bound(lo0, rs + tile_end, rdx[x.ta + x.nt - 1]) - lo0);
+          x.jlo = rdx[x.p0] - c0s;
+          x.jhi = rdx[x.p0 + x.nq - 1] - c0s;
+        }
         if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
           // "late" = the descendant sits one level below the target (finished only just before this level)
           if (!lookahead || S.sn_level[d] + 1 == S.sn_level[sfr]) late_tmp.push_back(x); else cd.push_back(x);
@@ -450,6 +464,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
 int set_attrs(scilmm_symbolic* sym, Dev* D) {
   if (D->attrs_set) return SCILMM_OK;
   const int big = 150 * 1024;
+  HIPCHK(hipFuncSetAttribute((const void*)k_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -507,6 +528,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     if (stc != SCILMM_OK) return stc;
   }
   const size_t sm_upd = sizeof(double) * (size_t)(2 * KC * LDA + 2 * KC * LDB) + sizeof(int32_t) * TM;
+  const size_t sm_potrf = sizeof(double) * (size_t)(NB * (NB + 1) + NB);
   hipStream_t st = D->stream;
   int64_t launches = 0;
   HIPCHK(hipEventRecord(D->ev[0], st));
@@ -584,7 +606,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
       // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
       const int64_t q0 = D->red_ptr_e[l], q1 = D->red_ptr_e[l + 1];
       if (q1 > q0) {
-        hipLaunchKernelGGL(k_reduce, dim3((unsigned)(16 * (q1 - q0))), dim3(128), 0, sd, D->v, D->d_red_tiles_e + q0,
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (q1 - q0))), dim3(128), 0, sd, D->v, D->d_red_tiles_e + q0,
                            D->d_tile_pslot_e, D->d_tile_pnseg_e, (const double*)(D->scratch + (size_t)(l & 1) * half), fac->L);
         launches++;
       }
@@ -613,14 +635,14 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
     const int64_t r0 = D->red_ptr[l], r1 = D->red_ptr[l + 1];
     if (r1 > r0) {
-      hipLaunchKernelGGL(k_reduce, dim3((unsigned)(16 * (r1 - r0))), dim3(128), 0, st, D->v, D->d_red_tiles + r0, D->d_tile_pslot,
+      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (r1 - r0))), dim3(128), 0, st, D->v, D->d_red_tiles + r0, D->d_tile_pslot,
                          D->d_tile_pnseg, (const double*)sh, fac->L);
       launches++;
     }
     launch_cells(st, 1, l);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
     if (f1 > f0) {
-      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
+      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
                          fac->invD, fac->logd, fac->status);
       launches++;
     }
@@ -706,6 +728,7 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     const int rc = std::min<int>(RPMAX, r - cbeg);
     const int rp = rp_of(rc);
     const unsigned gy = (unsigned)((rp + CW - 1) / CW);
+    const size_t sm_fwd = sizeof(double) * (size_t)(NB * LDW + KCS * LDA);
     const int64_t tot = (int64_t)S.n * rp;
     const unsigned pb = (unsigned)((tot + 255) / 256);
     if (mode == 0) {
@@ -724,16 +747,16 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         if (t1 == t0) continue;
         const bool atomic = (f1 - f0) > 1;
         if (mf && atomic)
-          hipLaunchKernelGGL((k_fwd<true, 0, true>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+          hipLaunchKernelGGL((k_fwd<true, 0, true>), dim3((unsigned)(t1 - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
                              fac->L, (const double*)D->X, D->W, rp);
         else if (mf)
-          hipLaunchKernelGGL((k_fwd<true, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+          hipLaunchKernelGGL((k_fwd<true, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
                              fac->L, (const double*)D->X, D->W, rp);
         else if (atomic)
-          hipLaunchKernelGGL((k_fwd<false, 0, true>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+          hipLaunchKernelGGL((k_fwd<false, 0, true>), dim3((unsigned)(t1 - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
                              fac->L, (const double*)D->X, D->W, rp);
         else
-          hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), 0, st, D->v, D->d_level_tiles + t0,
+          hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
                              fac->L, (const double*)D->X, D->W, rp);
       }
       if (!mid_recorded) {
@@ -767,10 +790,10 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
       HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, st));
       if (ntiles_all > 0) {
         if (mf)
-          hipLaunchKernelGGL((k_fwd<true, 1, true>), dim3((unsigned)ntiles_all, gy), dim3(256), 0, st, D->v, D->d_level_tiles, fac->L,
+          hipLaunchKernelGGL((k_fwd<true, 1, true>), dim3((unsigned)ntiles_all, gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
                              (const double*)D->W, D->X, rp);
         else
-          hipLaunchKernelGGL((k_fwd<false, 1, true>), dim3((unsigned)ntiles_all, gy), dim3(256), 0, st, D->v, D->d_level_tiles, fac->L,
+          hipLaunchKernelGGL((k_fwd<false, 1, true>), dim3((unsigned)ntiles_all, gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles, fac->L,
                              (const double*)D->W, D->X, rp);
       }
       hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);

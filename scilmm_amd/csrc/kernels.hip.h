@@ -13,7 +13,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #ifndef SCILMM_KC
-#define SCILMM_KC 16
+#define SCILMM_KC 32
+#endif
+#ifndef SCILMM_NB
+#define SCILMM_NB 128
 #endif
 #ifndef SCILMM_UPD_WAVES
 #define SCILMM_UPD_WAVES 2
@@ -24,8 +27,10 @@ namespace scilmm {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int NB = 64;        // max supernode block width (symbolic max_width must be <= NB)
+constexpr int NB = SCILMM_NB; // max supernode block width (symbolic max_width must be <= NB)
+constexpr int NJB = NB / 16;  // 16-column MFMA tiles across a block
 constexpr int TM = 128;       // target rows per tile
+constexpr int KCS = 16;       // k-chunk of the trsm / solve kernels
 constexpr int KC = SCILMM_KC;        // k-chunk staged through LDS (update kernel: 2 x 28 KB -> two workgroups per CU)
 constexpr int LDA = TM + 16;  // k-major LDS leading dims: (ld*8 B) == 128 mod 256 -> conflict-free b64 reads
 constexpr int LDB = NB + 16;
@@ -94,31 +99,30 @@ __global__ void k_add_diag(int32_t n, const int64_t* __restrict__ diag_dst, ValP
 // D[M=j][N=i]; wave wv owns target rows i in [32 wv, 32 wv + 32), all NB columns j.
 template <bool MFMA>
 __device__ __forceinline__ void tile_mma(const double* __restrict__ As, const double* __restrict__ Bs, int kc4, int ncb,
-                                         int lane, int wv, d4 (&acc)[4][2]) {
+                                         int lane, int wv, d4 (&acc)[NJB][2]) {
+  const int li = lane & 15, lk = lane >> 4;
   if (MFMA) {
-    const int li = lane & 15, lk = lane >> 4;
     const double* ap = As + lk * LDA + 32 * wv + li;
     const double* bp = Bs + lk * LDB + li;
-    if (ncb == 4) {
-      // full-width target block: straight-line body, all six LDS reads issued ahead of the eight MFMAs
+    if (ncb == NJB) {
+      // full-width target block: straight-line body, all LDS reads issued ahead of the MFMAs
 #pragma unroll 2
       for (int k4 = 0; k4 < kc4; k4 += 4) {
         const double b0 = ap[k4 * LDA], b1 = ap[k4 * LDA + 16];
-        const double a0 = bp[k4 * LDB], a1 = bp[k4 * LDB + 16], a2 = bp[k4 * LDB + 32], a3 = bp[k4 * LDB + 48];
-        acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-        acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-        acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-        acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-        acc[2][0] = mfma_f64(a2, b0, acc[2][0]);
-        acc[2][1] = mfma_f64(a2, b1, acc[2][1]);
-        acc[3][0] = mfma_f64(a3, b0, acc[3][0]);
-        acc[3][1] = mfma_f64(a3, b1, acc[3][1]);
+        double a[NJB];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) a[jb] = bp[k4 * LDB + 16 * jb];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) {
+          acc[jb][0] = mfma_f64(a[jb], b0, acc[jb][0]);
+          acc[jb][1] = mfma_f64(a[jb], b1, acc[jb][1]);
+        }
       }
     } else {
       for (int k4 = 0; k4 < kc4; k4 += 4) {
         const double b0 = ap[k4 * LDA], b1 = ap[k4 * LDA + 16];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
+        for (int jb = 0; jb < NJB; ++jb) {
           if (jb < ncb) {
             const double a = bp[k4 * LDB + 16 * jb];
             acc[jb][0] = mfma_f64(a, b0, acc[jb][0]);
@@ -129,15 +133,14 @@ __device__ __forceinline__ void tile_mma(const double* __restrict__ As, const do
     }
   } else {
     // scalar restatement of the same tile product in the same accumulator layout (debug path)
-    const int li = lane & 15, lr = lane >> 4;
     for (int k = 0; k < kc4; ++k) {
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb)
+      for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            acc[jb][ib][r] += Bs[k * LDB + 16 * jb + lr + 4 * r] * As[k * LDA + 32 * wv + 16 * ib + li];
+            acc[jb][ib][r] += Bs[k * LDB + 16 * jb + lk + 4 * r] * As[k * LDA + 32 * wv + 16 * ib + li];
     }
   }
 }
@@ -150,7 +153,7 @@ __device__ __forceinline__ void tile_mma(const double* __restrict__ As, const do
 // concatenated) is streamed in chunks of KC through a double-buffered LDS image: the global loads of
 // chunk i+1 are in flight in registers while chunk i feeds the MFMAs; one barrier per chunk.
 // A work item is (tile, combo range [cb,ce), slot): slot < 0 subtracts straight into the panel,
-// slot >= 0 writes the partial product to scratch (split-K; folded in by k_potrf / k_trsm loads).
+// slot >= 0 writes the partial product to scratch (split-K; folded in by k_reduce).
 struct ComboDesc {
   int64_t loff;     // L offset of the descendant panel
   int64_t rowoff;   // offset of its row list in sn_rows
@@ -159,6 +162,8 @@ struct ComboDesc {
   int32_t p0, nq;   // descendant rows [p0, p0+nq) are the target's columns
   int32_t ip0;      // >= 0: rows land at consecutive tile positions ip0..; -1: look each one up
   int32_t jp0;      // >= 0: columns land at consecutive target columns jp0..; -1: look each one up
+  int32_t ilo, ihi; // first / last tile position touched (rows are sorted, so everything lies in between)
+  int32_t jlo, jhi; // first / last target column touched
 };
 
 struct UpdWork {
@@ -170,37 +175,39 @@ struct UpdWork {
 constexpr int UPD_THREADS = 512;  // update kernel: eight waves per workgroup
 
 // Eight-wave variant of the tile product: wave wv owns 16 target rows, acc[jb] is the 16 x 16 tile of columns 16 jb..
+// jb0..jb1: 16-column tiles this chunk touches (the rest of the accumulators is skipped)
 template <bool MFMA>
-__device__ __forceinline__ void tile_mma8(const double* __restrict__ As, const double* __restrict__ Bs, int kc4, int ncb,
-                                          int lane, int wv, d4 (&acc)[4]) {
+__device__ __forceinline__ void tile_mma8(const double* __restrict__ As, const double* __restrict__ Bs, int kc4, int jb0,
+                                          int jb1, int lane, int wv, d4 (&acc)[NJB]) {
   const int li = lane & 15, lk = lane >> 4;
   if (MFMA) {
     const double* ap = As + lk * LDA + 16 * wv + li;
     const double* bp = Bs + lk * LDB + li;
-    if (ncb == 4) {
+    if (jb0 == 0 && jb1 == NJB - 1) {
 #pragma unroll 2
       for (int k4 = 0; k4 < kc4; k4 += 4) {
         const double b0 = ap[k4 * LDA];
-        const double a0 = bp[k4 * LDB], a1 = bp[k4 * LDB + 16], a2 = bp[k4 * LDB + 32], a3 = bp[k4 * LDB + 48];
-        acc[0] = mfma_f64(a0, b0, acc[0]);
-        acc[1] = mfma_f64(a1, b0, acc[1]);
-        acc[2] = mfma_f64(a2, b0, acc[2]);
-        acc[3] = mfma_f64(a3, b0, acc[3]);
+        double a[NJB];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) a[jb] = bp[k4 * LDB + 16 * jb];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) acc[jb] = mfma_f64(a[jb], b0, acc[jb]);
       }
     } else {
       for (int k4 = 0; k4 < kc4; k4 += 4) {
         const double b0 = ap[k4 * LDA];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-          if (jb < ncb) acc[jb] = mfma_f64(bp[k4 * LDB + 16 * jb], b0, acc[jb]);
+        for (int jb = 0; jb < NJB; ++jb)
+          if (jb >= jb0 && jb <= jb1) acc[jb] = mfma_f64(bp[k4 * LDB + 16 * jb], b0, acc[jb]);
       }
     }
   } else {
     for (int k = 0; k < kc4; ++k)
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb)
+      for (int jb = 0; jb < NJB; ++jb)
+        if (jb >= jb0 && jb <= jb1)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jb][r] += Bs[k * LDB + 16 * jb + lk + 4 * r] * As[k * LDA + 16 * wv + li];
+          for (int r = 0; r < 4; ++r) acc[jb][r] += Bs[k * LDB + 16 * jb + lk + 4 * r] * As[k * LDA + 16 * wv + li];
   }
 }
 
@@ -229,13 +236,13 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
   if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
   for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
   // eight waves: wave wv owns target rows [16 wv, 16 wv + 16) and all 64 columns (4 accumulator tiles)
-  d4 acc[4];
+  d4 acc[NJB];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int a = 0; a < NJB; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
   // this thread's fixed roles in the staging: A row t with k phase kpa (of KA); B column q with k phase kpb (of KB)
-  constexpr int KA = UPD_THREADS / 128, KB = UPD_THREADS / 64;
-  const int t = tid & 127, kpa = tid >> 7;
-  const int q = tid & 63, kpb = tid >> 6;
+  constexpr int KA = UPD_THREADS / TM, KB = UPD_THREADS / NB;
+  const int t = tid % TM, kpa = tid / TM;
+  const int q = tid % NB, kpb = tid / NB;
   // per-buffer record of what this thread wrote (so that it can clear exactly that)
   int w_ip[2] = {-1, -1}, w_jp[2] = {-1, -1}, w_kc[2] = {0, 0};
   // "next chunk" cursor
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
   };
   // uniform (per-workgroup) record of the mapping last staged into each buffer
   int u_ip0[2] = {-2, -2}, u_nt[2] = {0, 0}, u_jp0[2] = {-2, -2}, u_nq[2] = {0, 0}, u_kc[2] = {0, 0};
+  int s_ilo[2] = {0, 0}, s_ihi[2] = {TM - 1, TM - 1}, s_jb0[2] = {0, 0}, s_jb1[2] = {NJB - 1, NJB - 1};
   auto stage = [&](int b) {
     double* As = Abuf + b * KC * LDA;
     double* Bs = Bbuf + b * KC * LDB;
@@ -355,6 +363,10 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
     u_jp0[b] = dn.jp0;
     u_nq[b] = dn.nq;
     u_kc[b] = kcn;
+    s_ilo[b] = dn.ilo;
+    s_ihi[b] = dn.ihi;
+    s_jb0[b] = dn.jlo >> 4;
+    s_jb1[b] = min(dn.jhi >> 4, ncb - 1);
   };
   auto advance = [&]() -> bool {
     // move the cursor to the chunk after (cn, k0n); returns false at the end
@@ -379,8 +391,8 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
   int buf = 0;
   while (true) {
     if (more) prefetch();  // global loads of the next chunk in flight during the MFMAs
-    if (ABL != 1 && 16 * wv < nrow)
-      tile_mma8<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, ncb, lane, wv, acc);
+    if (ABL != 1 && 16 * wv <= s_ihi[buf] && 16 * wv + 15 >= s_ilo[buf])
+      tile_mma8<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, s_jb0[buf], s_jb1[buf], lane, wv, acc);
     if (!more) break;
     stage(buf ^ 1);
     kc4_cur = (kcn + 3) & ~3;
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
   if (wk.slot < 0) {
     double* P = L + S.sn_loff[s];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jb + lr + 4 * r;
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
   } else {
     double* Q = scratch + (int64_t)wk.slot * (TM * NB);
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+    for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jb + lr + 4 * r;
@@ -468,8 +480,8 @@ __global__ __launch_bounds__(128) void k_reduce(DevSym S, const int32_t* __restr
                                                 const int32_t* __restrict__ tile_pslot,
                                                 const int32_t* __restrict__ tile_pnseg, const double* __restrict__ scratch,
                                                 double* __restrict__ L) {
-  const int32_t g = red_tiles[blockIdx.x >> 4];
-  const int jg = (blockIdx.x & 15) * 4;
+  const int32_t g = red_tiles[blockIdx.x / (NB / 4)];
+  const int jg = (blockIdx.x % (NB / 4)) * 4;
   const int32_t s = S.tile_front[g];
   const int32_t ti = (int32_t)(g - S.tile_base[s]);
   const int32_t w = S.sn_start[s + 1] - S.sn_start[s];
@@ -520,8 +532,10 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   // transposed in the strict upper part, X(r,c) = T[c][r] for r > c, with its diagonal in xd[].  34 KB, so a
   // potrf workgroup fits on a CU next to two update workgroups (look-ahead keeps those resident).
   constexpr int LD = NB + 1;
-  __shared__ double T[NB * LD];
-  __shared__ double xd[NB];
+  constexpr int NQ = (NB / 16 > 1) ? (NB / 16 - 1) : 1;  // register slots per thread in the blocked phases
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* T = smem;             // [NB][LD]
+  double* xd = smem + NB * LD;  // [NB]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t s = fronts[blockIdx.x];
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
@@ -580,9 +594,9 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     const int nrem = W - o - 16;
     if (nrem > 0) {
       // ---- panel below: B = A * Dinv^T   (B[i][c] = sum_{k<=c} A[i][k] Dinv[c][k])
-      double tmp[3];
+      double tmp[NQ];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int idx = tid + 256 * q;
         tmp[q] = 0.0;
         if (idx < nrem * 16) {
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int idx = tid + 256 * q;
         if (idx < nrem * 16) T[(o + 16 + (idx >> 4)) * LD + o + (idx & 15)] = tmp[q];
       }
@@ -616,9 +630,9 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   // ---- inverse of the whole block by block sub-diagonals: X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj
   for (int d = 1; d < nb; ++d) {
     const int nblk = nb - d;
-    double tmp[3];
+    double tmp[NQ];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int idx = tid + 256 * q;
       tmp[q] = 0.0;
       if (idx < nblk * 256) {
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int idx = tid + 256 * q;
       if (idx < nblk * 256) {
         const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int idx = tid + 256 * q;
       tmp[q] = 0.0;
       if (idx < nblk * 256) {
@@ -656,7 +670,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int idx = tid + 256 * q;
       if (idx < nblk * 256) {
         const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
@@ -685,8 +699,8 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
                                               const double* __restrict__ invD) {
-  __shared__ __attribute__((aligned(16))) double As[KC * LDA];
-  __shared__ __attribute__((aligned(16))) double Bs[KC * LDB];
+  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t g = tiles[blockIdx.x];
   const int32_t s = S.tile_front[g];
@@ -699,13 +713,13 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
   const int ncb = (w + 15) >> 4;
   double* P = L + S.sn_loff[s];
   const double* I = invD + S.inv_off[s];
-  d4 acc[4][2];
+  d4 acc[NJB][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NJB; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int32_t k0 = 0; k0 < w; k0 += KC) {
-    const int kc = min(KC, w - k0);
+  for (int32_t k0 = 0; k0 < w; k0 += KCS) {
+    const int kc = min(KCS, w - k0);
     const int kc4 = (kc + 3) & ~3;
     if (k0 > 0) __syncthreads();
     for (int idx = tid + kc * LDA; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
@@ -715,16 +729,16 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
       const int t = tid & 127;
       if (t < nrow)
         for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + t] = P[(int64_t)(k0 + k) * m + R0 + t];
-      const int q = tid & 63;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
+      const int q = tid % NB;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
       if (q < w)
-        for (int k = tid >> 6; k < kc; k += 4) Bs[k * LDB + q] = I[(k0 + k) * w + q];
+        for (int k = tid / NB; k < kc; k += 256 / NB) Bs[k * LDB + q] = I[(k0 + k) * w + q];
     }
     __syncthreads();
     if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
   }
   const int li = lane & 15, lr = lane >> 4;
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb)
+  for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -799,8 +813,7 @@ template <bool MFMA, bool TRANS>
 __global__ __launch_bounds__(256) void k_diag_solve(DevSym S, const int32_t* __restrict__ fronts,
                                                     const double* __restrict__ invD, const double* Yin, double* Xout,
                                                     int32_t rp) {
-  __shared__ __attribute__((aligned(16))) double Is[NB * LDB];  // Is[k*LDB + j] = op(invL)[j][k]
-  __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];
+  __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // y_s, [k][c]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c_lo = blockIdx.y * CW;
   const int rpl = min(CW, rp - c_lo);
@@ -815,29 +828,47 @@ __global__ __launch_bounds__(256) void k_diag_solve(DevSym S, const int32_t* __r
     if (c < LDW)
       for (int k = tid >> 6; k < w4; k += 4)
         Ys[k * LDW + c] = (k < w && c < rpl) ? Yin[(int64_t)(c0 + k) * rp + c_lo + c] : 0.0;
-    const int j = tid & 63;
-    for (int k = tid >> 6; k < w4; k += 4) {
-      double v = 0.0;
-      if (k < w && j < w) v = TRANS ? I[j * w + k] : I[k * w + j];
-      Is[k * LDB + j] = v;
-    }
   }
   __syncthreads();
-  d4 xa[NCT];
+  const int li = lane & 15, lk = lane >> 4;
+  // row blocks of 16 are dealt round-robin to the four waves; the A operand op(invL)[j][k] (w x w,
+  // column-major, L2-resident) is read straight into the MFMA fragment: lane (li, lk) needs element
+  // (16 jb + li, k4 + lk)
+  for (int jb = wv; 16 * jb < w; jb += 4) {
+    d4 xa[NCT];
 #pragma unroll
-  for (int cn = 0; cn < NCT; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
-  if (16 * wv < w) {
-    const int kbeg = TRANS ? 16 * wv : 0;
-    const int kend = TRANS ? w4 : min(w4, 16 * (wv + 1));
-    rhs_mma<MFMA, NCT>(Is + kbeg * LDB, LDB, 16 * wv, Ys + kbeg * LDW, LDW, kend - kbeg, ncn, lane, xa);
-    const int li = lane & 15, lr = lane >> 4;
+    for (int cn = 0; cn < NCT; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int kbeg = TRANS ? 16 * jb : 0;
+    const int kend = TRANS ? w4 : min(w4, 16 * (jb + 1));
+    const int j = 16 * jb + li;
+    if (MFMA) {
+      for (int k4 = kbeg; k4 < kend; k4 += 4) {
+        const int k = k4 + lk;
+        double a = 0.0;
+        if (j < w && k < w) a = TRANS ? I[(int64_t)j * w + k] : I[(int64_t)k * w + j];
+#pragma unroll
+        for (int cn = 0; cn < NCT; ++cn)
+          if (cn < ncn) xa[cn] = mfma_f64(a, Ys[k * LDW + 16 * cn + li], xa[cn]);
+      }
+    } else {
+      for (int k = kbeg; k < kend && k < w; ++k)
+#pragma unroll
+        for (int cn = 0; cn < NCT; ++cn)
+          if (cn < ncn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int jr = 16 * jb + lk + 4 * r;
+              const double a = (jr < w) ? (TRANS ? I[(int64_t)jr * w + k] : I[(int64_t)k * w + jr]) : 0.0;
+              xa[cn][r] += a * Ys[k * LDW + 16 * cn + li];
+            }
+    }
 #pragma unroll
     for (int cn = 0; cn < NCT; ++cn)
       if (cn < ncn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = 16 * wv + lr + 4 * r;
-          if (j < w) Xout[(int64_t)(c0 + j) * rp + c_lo + 16 * cn + li] = xa[cn][r];
+          const int jr = 16 * jb + lk + 4 * r;
+          if (jr < w) Xout[(int64_t)(c0 + jr) * rp + c_lo + 16 * cn + li] = xa[cn][r];
         }
   }
 }
@@ -850,8 +881,9 @@ __global__ __launch_bounds__(256) void k_diag_solve(DevSym S, const int32_t* __r
 template <bool MFMA, int MODE, bool ATOMIC>
 __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
                                              const double* Xin, double* W, int32_t rp) {
-  __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // x_s (or R_s), [k][c]
-  __shared__ __attribute__((aligned(16))) double As[KC * LDA];  // panel chunk, [k][row]
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ys = smem;             // [NB][LDW]  x_s (or R_s), [k][c]
+  double* As = smem + NB * LDW;  // [KCS][LDA]  panel chunk, [k][row]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c_lo = blockIdx.y * CW;
   const int rpl = min(CW, rp - c_lo);
@@ -881,8 +913,8 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
     a0[cn] = (d4){0.0, 0.0, 0.0, 0.0};
     a1[cn] = (d4){0.0, 0.0, 0.0, 0.0};
   }
-  for (int32_t k0 = 0; k0 < w; k0 += KC) {
-    const int kc = min(KC, w - k0);
+  for (int32_t k0 = 0; k0 < w; k0 += KCS) {
+    const int kc = min(KCS, w - k0);
     const int kc4 = (kc + 3) & ~3;
     if (k0 > 0) __syncthreads();
     {
@@ -935,9 +967,12 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
   const int32_t cd = S.sn_start[d], wd = S.sn_start[d + 1] - cd;
   const double* Pd = L + S.sn_loff[d];
   const int ncn = rpl >> 4;
-  d4 acc[NCT];
+  constexpr int NH = (NJB + 3) / 4;  // row blocks (of the descendant's columns) per wave
+  d4 acc[NH][NCT];
 #pragma unroll
-  for (int cn = 0; cn < NCT; ++cn) acc[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int cn = 0; cn < NCT; ++cn) acc[h][cn] = (d4){0.0, 0.0, 0.0, 0.0};
   for (int32_t q0 = p0; q0 < p1; q0 += 32) {
     const int qn = min(32, p1 - q0);
     const int qn4 = (qn + 3) & ~3;
@@ -952,36 +987,47 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
           Xg[q2 * LDW + c] = (q2 < qn && c < rpl) ? X[(int64_t)rd[q0 + q2] * rp + c_lo + c] : 0.0;
     }
     __syncthreads();
-    if (16 * wv < wd) {
-      // D[M=k][N=c] += sum_q Ps[k][q] * Xg[q][c];  Aop[k][q] read as Ps[(16 wv + l&15)*LDP + q4 + (l>>4)]
-      const int li = lane & 15, lk = lane >> 4;
-      if (MFMA) {
-        for (int q4 = 0; q4 < qn4; q4 += 4) {
-          const double a = Ps[(16 * wv + li) * LDP + q4 + lk];
+    // D[M=k][N=c] += sum_q Ps[k][q] * Xg[q][c];  Aop[k][q] read as Ps[(16 kb + l&15)*LDP + q4 + (l>>4)]
+    const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-          for (int cn = 0; cn < NCT; ++cn)
-            if (cn < ncn) acc[cn] = mfma_f64(a, Xg[(q4 + lk) * LDW + 16 * cn + li], acc[cn]);
+    for (int h = 0; h < NH; ++h) {
+      const int kb = wv + 4 * h;
+      if (16 * kb < wd) {
+        if (MFMA) {
+          for (int q4 = 0; q4 < qn4; q4 += 4) {
+            const double a = Ps[(16 * kb + li) * LDP + q4 + lk];
+#pragma unroll
+            for (int cn = 0; cn < NCT; ++cn)
+              if (cn < ncn) acc[h][cn] = mfma_f64(a, Xg[(q4 + lk) * LDW + 16 * cn + li], acc[h][cn]);
+          }
+        } else {
+          for (int q = 0; q < qn4; ++q)
+#pragma unroll
+            for (int cn = 0; cn < NCT; ++cn)
+              if (cn < ncn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  acc[h][cn][r] += Ps[(16 * kb + lk + 4 * r) * LDP + q] * Xg[q * LDW + 16 * cn + li];
         }
-      } else {
-        for (int q = 0; q < qn4; ++q)
-#pragma unroll
-          for (int cn = 0; cn < NCT; ++cn)
-            if (cn < ncn)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[cn][r] += Ps[(16 * wv + lk + 4 * r) * LDP + q] * Xg[q * LDW + 16 * cn + li];
       }
     }
   }
-  if (16 * wv < wd) {
+  {
     const int li = lane & 15, lr = lane >> 4;
 #pragma unroll
-    for (int cn = 0; cn < NCT; ++cn)
-      if (cn < ncn)
+    for (int h = 0; h < NH; ++h) {
+      const int kb = wv + 4 * h;
+      if (16 * kb < wd) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * wv + lr + 4 * r;
-          if (k < wd) X[(int64_t)(cd + k) * rp + c_lo + 16 * cn + li] -= acc[cn][r];
-        }
+        for (int cn = 0; cn < NCT; ++cn)
+          if (cn < ncn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = 16 * kb + lr + 4 * r;
+              if (k < wd) X[(int64_t)(cd + k) * rp + c_lo + 16 * cn + li] -= acc[h][cn][r];
+            }
+      }
+    }
   }
 }
 

@@ -2,6 +2,9 @@
 // Built once per sparsity pattern (the reference redoes it on every evaluation:
 // scilmm/SparseCholesky.py:22-26,92).
 #pragma once
+#ifndef SCILMM_NB
+#define SCILMM_NB 128
+#endif
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -17,7 +20,7 @@ struct SymbolicOptions {
   int32_t relax_w2 = 48;       // merged width <= relax_w2 -> allow zero fraction z2
   double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.05;
   double amd_dense = 10.0;     // rows with degree > amd_dense*sqrt(n) are ordered last
-  int32_t max_width = 64;      // split supernodes wider than this (0 = unlimited)
+  int32_t max_width = SCILMM_NB; // split supernodes wider than this (the kernels' block width; 0 = unlimited)
   int32_t tile_rows = 128;     // rows per target tile of the update kernel
 };
 
