@@ -532,7 +532,6 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   // transposed in the strict upper part, X(r,c) = T[c][r] for r > c, with its diagonal in xd[].  34 KB, so a
   // potrf workgroup fits on a CU next to two update workgroups (look-ahead keeps those resident).
   constexpr int LD = NB + 1;
-  constexpr int NQ = (NB / 16 > 1) ? (NB / 16 - 1) : 1;  // register slots per thread in the blocked phases
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* T = smem;             // [NB][LD]
   double* xd = smem + NB * LD;  // [NB]
@@ -593,89 +592,81 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     __syncthreads();
     const int nrem = W - o - 16;
     if (nrem > 0) {
-      // ---- panel below: B = A * Dinv^T   (B[i][c] = sum_{k<=c} A[i][k] Dinv[c][k])
-      double tmp[NQ];
+      const int nbr = nrem >> 4;
+      const int li = lane & 15, lk = lane >> 4;
+      // ---- panel below: B_ib = A_ib * Dinv^T, one wave per 16-row block, MFMA, in place
+      //      D[m][n] = sum_k A[m][k] Dinv[n][k];  Dinv[n][k] = X(o+n, o+k), lower triangular, diagonal in xd
+      for (int ib = wv; ib < nbr; ib += 4) {
+        const int r0 = o + 16 + 16 * ib;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + 256 * q;
-        tmp[q] = 0.0;
-        if (idx < nrem * 16) {
-          const int i = o + 16 + (idx >> 4), c = idx & 15;
-          double sum = T[i * LD + o + c] * xd[o + c];
-          for (int k = 0; k < c; ++k) sum += T[i * LD + o + k] * T[(o + k) * LD + o + c];
-          tmp[q] = sum;
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+          const int k = k4 + lk;
+          const double av = T[(r0 + li) * LD + o + k];
+          const double bv = (k < li) ? T[(o + k) * LD + o + li] : ((k == li) ? xd[o + li] : 0.0);
+          acc = mfma_f64(av, bv, acc);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(r0 + lk + 4 * r) * LD + o + li] = acc[r];
       }
       __syncthreads();
+      // ---- trailing update, lower block pairs (ib >= kk): C_{ib,kk} -= B_ib * B_kk^T (MFMA)
+      int pidx = 0;
+      for (int ib = 0; ib < nbr; ++ib)
+        for (int kk = 0; kk <= ib; ++kk, ++pidx) {
+          if ((pidx & 3) != wv) continue;
+          const int r0 = o + 16 + 16 * ib, q0 = o + 16 + 16 * kk;
+          d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + 256 * q;
-        if (idx < nrem * 16) T[(o + 16 + (idx >> 4)) * LD + o + (idx & 15)] = tmp[q];
-      }
-      __syncthreads();
-      // ---- trailing update (lower part): A[i][k'] -= sum_c B[i][c] B[k'][c]
-      for (int idx = tid; idx < nrem * nrem; idx += 256) {
-        const int ii = idx / nrem, kk = idx - ii * nrem;
-        if (kk <= ii) {
-          const int i = o + 16 + ii, k2 = o + 16 + kk;
-          double sum = 0.0;
+          for (int k4 = 0; k4 < 16; k4 += 4) {
+            const double av = T[(r0 + li) * LD + o + k4 + lk];
+            const double bv = T[(q0 + li) * LD + o + k4 + lk];
+            acc = mfma_f64(av, bv, acc);
+          }
 #pragma unroll
-          for (int c = 0; c < 16; ++c) sum += T[i * LD + o + c] * T[k2 * LD + o + c];
-          T[i * LD + k2] -= sum;
+          for (int r = 0; r < 4; ++r) {
+            const int row = r0 + lk + 4 * r, col = q0 + li;
+            if (row >= col) T[row * LD + col] -= acc[r];  // the strict upper part belongs to the inverse
+          }
         }
-      }
       __syncthreads();
     }
   }
-  // ---- inverse of the whole block by block sub-diagonals: X_ij = -X_ii * sum_{k=j}^{i-1} L_ik X_kj
+  // ---- inverse of the whole block by block sub-diagonals: X_ij = -X_ii * sum_{kb=j}^{i-1} L_{i,kb} X_{kb,j}
+  //      one wave per 16 x 16 block (i = j + d): both products are MFMA chains; the intermediate goes through
+  //      the block's own LDS cells (same wave, in-order LDS => no workgroup barrier inside a sub-diagonal)
   for (int d = 1; d < nb; ++d) {
     const int nblk = nb - d;
-    double tmp[NQ];
+    const int li = lane & 15, lk = lane >> 4;
+    for (int blk = wv; blk < nblk; blk += 4) {
+      const int i0 = (blk + d) << 4, j0 = blk << 4;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int kb0 = j0; kb0 < i0; kb0 += 16) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int idx = tid + 256 * q;
-      tmp[q] = 0.0;
-      if (idx < nblk * 256) {
-        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
-        const int i0 = (blk + d) << 4, j0 = blk << 4;
-        const int col = j0 + cc;
-        // X(kk, col) is zero for kk < col
-        double sum = T[(i0 + rr) * LD + col] * xd[col];
-        for (int kk = col + 1; kk < i0; ++kk) sum += T[(i0 + rr) * LD + kk] * T[col * LD + kk];
-        tmp[q] = sum;
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+          const int k = kb0 + k4 + lk;               // global column of L / row of X
+          const double av = T[(i0 + li) * LD + k];   // L(i0+li, k)
+          const int col = j0 + li;                   // X(k, col)
+          const double bv = (k > col) ? T[col * LD + k] : ((k == col) ? xd[col] : 0.0);
+          acc = mfma_f64(av, bv, acc);
+        }
       }
-    }
-    __syncthreads();
+      // temp(i0 + row, j0 + col) parked at X's own cells: X(r, c) = T[c][r]
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < nblk * 256) {
-        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
-        T[((blk << 4) + cc) * LD + ((blk + d) << 4) + rr] = tmp[q];  // temp at X(i0+rr, j0+cc)
-      }
-    }
-    __syncthreads();
+      for (int r = 0; r < 4; ++r) T[(j0 + li) * LD + i0 + lk + 4 * r] = acc[r];
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      d4 acc2 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int idx = tid + 256 * q;
-      tmp[q] = 0.0;
-      if (idx < nblk * 256) {
-        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
-        const int i0 = (blk + d) << 4, j0 = blk << 4;
-        // sum_kk X(i0+rr, i0+kk) * temp(i0+kk, j0+cc), X_ii lower triangular: kk <= rr
-        double sum = xd[i0 + rr] * T[(j0 + cc) * LD + i0 + rr];
-        for (int kk = 0; kk < rr; ++kk) sum += T[(i0 + kk) * LD + i0 + rr] * T[(j0 + cc) * LD + i0 + kk];
-        tmp[q] = -sum;
+      for (int k4 = 0; k4 < 16; k4 += 4) {
+        const int k = k4 + lk;
+        // X_ii(m = li, k): lower triangular
+        const double av = (k < li) ? T[(i0 + k) * LD + i0 + li] : ((k == li) ? xd[i0 + li] : 0.0);
+        const double bv = T[(j0 + li) * LD + i0 + k];  // temp(i0 + k, j0 + li)
+        acc2 = mfma_f64(av, bv, acc2);
       }
-    }
-    __syncthreads();
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int idx = tid + 256 * q;
-      if (idx < nblk * 256) {
-        const int blk = idx >> 8, e = idx & 255, rr = e >> 4, cc = e & 15;
-        T[((blk << 4) + cc) * LD + ((blk + d) << 4) + rr] = tmp[q];
-      }
+      for (int r = 0; r < 4; ++r) T[(j0 + li) * LD + i0 + lk + 4 * r] = -acc2[r];
     }
     __syncthreads();
   }
