@@ -58,6 +58,7 @@ struct Dev {
   int32_t* d_tile_pnseg_e = nullptr;
   int32_t* d_red_tiles_e = nullptr;
   std::vector<int64_t> red_ptr_e;
+  std::vector<int64_t> lev_cost_e, lev_cost_l;  // per-level dense update cost units (diagnostics)
   double* scratch = nullptr;       // max slots per level * TM*NB doubles
   int32_t* d_red_tiles = nullptr;  // tiles that carry partial slabs, grouped by level
   // cell-wise path for small update pairs: set 0 = early (side stream), set 1 = late (main stream)
@@ -75,6 +76,7 @@ struct Dev {
   std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
   int ablate = 0;
+  int update_variant = 1;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   std::vector<hipEvent_t> pev;     // 4 events per level when profiling
 };
@@ -181,6 +183,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   D->use_mfma = !(nm && nm[0] == '1');
   const char* ab = getenv("SCILMM_ABLATE");
   D->ablate = ab ? atoi(ab) : 0;
+  const char* uv = getenv("SCILMM_UPDATE_VARIANT");
+  if (uv) D->update_variant = atoi(uv);
   D->v.n = S.n;
   D->v.nsuper = S.nsuper;
   int st;
@@ -422,6 +426,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         }
       }
       max_slots = std::max(max_slots, slots);
+      D->lev_cost_e.push_back(total_e);
+      D->lev_cost_l.push_back(total_l);
       D->work_ptr[l + 1] = (int64_t)work.size();
       D->early_ptr[l + 1] = (int64_t)work_early.size();
       D->red_ptr[l + 1] = (int64_t)red_tiles.size();
@@ -471,6 +477,8 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -571,8 +579,12 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
       hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     else if (D->use_mfma && D->ablate == 2)
       hipLaunchKernelGGL((k_update<true, 2>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+    else if (D->use_mfma && D->update_variant == 2)
+      hipLaunchKernelGGL((k_update2<true>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     else if (D->use_mfma)
       hipLaunchKernelGGL((k_update<true, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+    else if (D->update_variant == 2)
+      hipLaunchKernelGGL((k_update2<false>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     else
       hipLaunchKernelGGL((k_update<false, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     launches++;
@@ -699,6 +711,25 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     D->timing.trsm_ms = tt;
     D->timing.reduce_cells_ms = tmid;
     D->timing.n_update_launches = nu;
+    if (const char* dump = getenv("SCILMM_LEVEL_DUMP")) {
+      // diagnostic: one line per level (durations in ms; cost = combos + K-chunks of the level's dense work)
+      if (FILE* fp = fopen(dump, "w")) {
+        fprintf(fp, "level,fronts,tiles,items_early,items_late,cost_early,cost_late,early_ms,late_ms,mid_ms,potrf_ms,trsm_ms\n");
+        for (int32_t l = 0; l < S.nlevels; ++l) {
+          float xe = 0, xl = 0, xm = 0, xp = 0, xt = 0;
+          if (D->work_ptr[l + 1] > D->work_ptr[l]) HIPCHK(hipEventElapsedTime(&xl, D->pev[PE * l + 0], D->pev[PE * l + 1]));
+          if (D->early_ptr[l + 1] > D->early_ptr[l]) HIPCHK(hipEventElapsedTime(&xe, D->pev[PE * l + 5], D->pev[PE * l + 6]));
+          HIPCHK(hipEventElapsedTime(&xm, D->pev[PE * l + 1], D->pev[PE * l + 2]));
+          HIPCHK(hipEventElapsedTime(&xp, D->pev[PE * l + 2], D->pev[PE * l + 3]));
+          HIPCHK(hipEventElapsedTime(&xt, D->pev[PE * l + 3], D->pev[PE * l + 4]));
+          fprintf(fp, "%d,%d,%lld,%lld,%lld,%lld,%lld,%.4f,%.4f,%.4f,%.4f,%.4f\n", l, S.level_ptr[l + 1] - S.level_ptr[l],
+                  (long long)(S.level_tile_ptr[l + 1] - S.level_tile_ptr[l]), (long long)(D->early_ptr[l + 1] - D->early_ptr[l]),
+                  (long long)(D->work_ptr[l + 1] - D->work_ptr[l]), (long long)D->lev_cost_e[l], (long long)D->lev_cost_l[l], xe, xl,
+                  xm, xp, xt);
+        }
+        fclose(fp);
+      }
+    }
   }
   if (status != 0x7fffffff) {
     if (bad_col) *bad_col = status;

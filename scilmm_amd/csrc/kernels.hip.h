@@ -426,6 +426,224 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_update2: same contract as k_update, different schedule.  fp64 MFMA issue blocks on the matrix pipe
+// (~100 cycles per v_mfma_f64_16x16x4_f64 per SIMD), so instructions placed BETWEEN the MFMAs of a k-step are
+// nearly free.  The staging of the next chunk is therefore cut into KC/4 pieces and spread over the k-steps of
+// the current chunk: piece i of chunk c+1 goes registers -> LDS (other buffer) and the same registers are at
+// once re-loaded with piece i of chunk c+2 from global memory, one chunk of MFMA time ahead of its use.
+// One register set, one barrier per chunk (two when the target mapping of the incoming chunk differs from what
+// the LDS buffer holds: every thread first clears its own old cells, see k_update).
+template <bool MFMA>
+__global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update2(DevSym S, const UpdWork* __restrict__ work,
+                                                 const ComboDesc* __restrict__ combos, double* __restrict__ L,
+                                                 double* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Abuf = smem;                         // [2][KC*LDA]
+  double* Bbuf = smem + 2 * KC * LDA;          // [2][KC*LDB]
+  int32_t* rowlab = (int32_t*)(smem + 2 * KC * LDA + 2 * KC * LDB);  // [TM]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const UpdWork wk = work[blockIdx.x];
+  const int32_t g = wk.tile;
+  const int64_t cb = wk.cb, ce = wk.ce;
+  if (cb >= ce) return;
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  const int ncb = (w + 15) >> 4;
+  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
+  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
+  d4 acc[NJB];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+  constexpr int KA = UPD_THREADS / TM, KB = UPD_THREADS / NB;
+  constexpr int NPA = KC / KA, NPB = KC / KB, NS = KC / 4;  // pieces of A / B per thread, k-steps per chunk
+  static_assert(NPA <= NS && NPB <= NS, "staging pieces must fit the k-steps of a chunk");
+  const int t = tid % TM, kpa = tid / TM;
+  const int q = tid % NB, kpb = tid / NB;
+  // ---- three pipeline stages: L = being loaded into registers, W = being written to LDS, C = being multiplied
+  struct Stage {
+    int ip, jp, kc;              // this thread's tile row / target column (-1: none) and the chunk depth
+    int la, lb;                  // LDS cell offsets: the row / column, or this thread's private pad cell
+    int ip0, nt, jp0, nq;        // uniform mapping (for the same-cells test)
+    int ilo, ihi, jb0, jb1;      // spans (for MFMA skipping)
+    bool valid;
+  };
+  Stage SL{}, SW{}, SC{};
+  int64_t cn = cb;  // cursor of the load stage
+  int k0n = 0;
+  ComboDesc dn = combos[cn];
+  ComboDesc dnext = combos[min(cn + 1, ce - 1)];
+  const double* gpa = nullptr;  // this thread's global read pointers for the load-stage chunk
+  const double* gpb = nullptr;
+  int64_t gmd = 0;
+  auto locate_L = [&]() {
+    SL.valid = true;
+    SL.ip = -1;
+    SL.jp = -1;
+    if (t < dn.nt) {
+      if (dn.ip0 >= 0) {
+        SL.ip = dn.ip0 + t;
+      } else {
+        const int32_t lab = S.sn_rows[dn.rowoff + dn.ta + t];
+        int lo = 0, hi = nrow;
+        while (lo < hi) {
+          int mid = (lo + hi) >> 1;
+          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
+        }
+        SL.ip = lo;
+      }
+    }
+    if (q < dn.nq) SL.jp = (dn.jp0 >= 0) ? dn.jp0 + q : S.sn_rows[dn.rowoff + dn.p0 + q] - c0;
+    SL.la = SL.ip >= 0 ? SL.ip : TM + (t & 15);
+    SL.lb = SL.jp >= 0 ? SL.jp : NB + (q & 15);
+    SL.ip0 = dn.ip0; SL.nt = dn.nt; SL.jp0 = dn.jp0; SL.nq = dn.nq;
+    SL.ilo = dn.ilo; SL.ihi = dn.ihi; SL.jb0 = dn.jlo >> 4; SL.jb1 = min(dn.jhi >> 4, ncb - 1);
+  };
+  auto point_L = [&]() {
+    SL.kc = min(KC, dn.wd - k0n);
+    gmd = dn.md;
+    const double* Pd = L + dn.loff + (int64_t)k0n * gmd;
+    // threads without a row / column of this combo read a valid neighbour's element (the value is never used:
+    // it lands in that thread's private LDS pad cell), so the hot loop needs no per-thread predicate
+    gpa = Pd + dn.ta + (SL.ip >= 0 ? t : 0);
+    gpb = Pd + dn.p0 + (SL.jp >= 0 ? q : 0);
+  };
+  auto advance_L = [&]() {
+    // move the load cursor to the next chunk; invalidates SL at the end of the work item
+    k0n += KC;
+    if (k0n >= dn.wd) {
+      ++cn;
+      k0n = 0;
+      if (cn >= ce) { SL.valid = false; return; }
+      dn = dnext;
+      dnext = combos[min(cn + 1, ce - 1)];
+      locate_L();
+    }
+    point_L();
+  };
+  double ra[NPA], rb[NPB];
+  // branch-free pieces: k is clamped into the chunk for the load, and rows beyond the chunk depth are written as
+  // zeros (so every cell a thread owns in a buffer is rewritten by every chunk: no stale k rows)
+  auto load_piece = [&](int i) {
+    if (i < NPA) ra[i] = gpa[(int64_t)min(kpa + KA * i, SL.kc - 1) * gmd];
+    if (i < NPB) rb[i] = gpb[(int64_t)min(kpb + KB * i, SL.kc - 1) * gmd];
+  };
+  auto write_piece = [&](int i, double* As, double* Bs) {
+    if (i < NPA) As[(kpa + KA * i) * LDA + SW.la] = (kpa + KA * i < SW.kc) ? ra[i] : 0.0;
+    if (i < NPB) Bs[(kpb + KB * i) * LDB + SW.lb] = (kpb + KB * i < SW.kc) ? rb[i] : 0.0;
+  };
+  // what each LDS buffer currently holds (per-thread cells + uniform mapping)
+  int h_ip[2] = {-1, -1}, h_jp[2] = {-1, -1}, h_kc[2] = {0, 0};
+  int u_ip0[2] = {-2, -2}, u_nt[2] = {0, 0}, u_jp0[2] = {-2, -2}, u_nq[2] = {0, 0};
+  auto same_cells = [&](int b) -> bool {
+    return SW.ip0 >= 0 && SW.ip0 == u_ip0[b] && SW.nt == u_nt[b] && SW.jp0 >= 0 && SW.jp0 == u_jp0[b] && SW.nq == u_nq[b];
+  };
+  auto clear_own = [&](int b) {
+    double* As = Abuf + b * KC * LDA;
+    double* Bs = Bbuf + b * KC * LDB;
+    if (h_ip[b] >= 0) {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) As[(kpa + KA * i) * LDA + h_ip[b]] = 0.0;
+    }
+    if (h_jp[b] >= 0) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) Bs[(kpb + KB * i) * LDB + h_jp[b]] = 0.0;
+    }
+  };
+  auto record = [&](int b) {
+    h_ip[b] = SW.ip; h_jp[b] = SW.jp; h_kc[b] = SW.kc;
+    u_ip0[b] = SW.ip0; u_nt[b] = SW.nt; u_jp0[b] = SW.jp0; u_nq[b] = SW.nq;
+  };
+  __syncthreads();  // rowlab + zeroed buffers visible
+  // ---- prologue: chunk 0 -> registers -> buffer 0; chunk 1 -> registers
+  locate_L();
+  point_L();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) load_piece(i);
+  SW = SL;
+  advance_L();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) write_piece(i, Abuf, Bbuf);
+  record(0);
+  if (SL.valid) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) load_piece(i);
+  }
+  SC = SW;
+  SW = SL;
+  if (SL.valid) advance_L();
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    double* Aw = Abuf + (buf ^ 1) * KC * LDA;
+    double* Bw = Bbuf + (buf ^ 1) * KC * LDB;
+    if (SW.valid && !same_cells(buf ^ 1)) {
+      clear_own(buf ^ 1);
+      __syncthreads();
+    }
+    const double* Ac = Abuf + buf * KC * LDA;
+    const double* Bc = Bbuf + buf * KC * LDB;
+    const int kc4 = (SC.kc + 3) & ~3;
+    const bool mine = (16 * wv <= SC.ihi) && (16 * wv + 15 >= SC.ilo);
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (SW.valid) write_piece(i, Aw, Bw);
+      if (SL.valid) load_piece(i);
+      if (mine && 4 * i < kc4) {
+        if (MFMA) {
+          const double b0 = Ac[(4 * i + lk) * LDA + 16 * wv + li];
+#pragma unroll
+          for (int jb = 0; jb < NJB; ++jb)
+            if (jb >= SC.jb0 && jb <= SC.jb1) acc[jb] = mfma_f64(Bc[(4 * i + lk) * LDB + 16 * jb + li], b0, acc[jb]);
+        } else {
+          for (int k = 4 * i; k < 4 * i + 4; ++k)
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb)
+              if (jb >= SC.jb0 && jb <= SC.jb1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[jb][r] += Bc[k * LDB + 16 * jb + lk + 4 * r] * Ac[k * LDA + 16 * wv + li];
+        }
+      }
+    }
+    if (!SW.valid) break;
+    record(buf ^ 1);
+    SC = SW;
+    SW = SL;
+    if (SL.valid) advance_L();
+    __syncthreads();
+    buf ^= 1;
+  }
+  // epilogue: identical to k_update
+  const int li = lane & 15, lr = lane >> 4;
+  if (wk.slot < 0) {
+    double* P = L + S.sn_loff[s];
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 16 * wv + li;
+        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][r];
+      }
+  } else {
+    double* Q = scratch + (int64_t)wk.slot * (TM * NB);
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 16 * wv + li;
+        Q[j * TM + i] = acc[jb][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cell-wise path for the small update pairs (a few rows x a few columns of a narrow descendant): the host
 // groups every contributed target cell by address; one thread owns one target cell and subtracts the dot
 // products  sum_k L_d[t,k] L_d[q,k]  of all its contributions in a fixed order.  No LDS, no barriers, no

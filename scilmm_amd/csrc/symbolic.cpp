@@ -320,7 +320,8 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         double frac = (double)z / tot;
         bool merge = (wnew <= opts.relax_small) || (wnew <= opts.relax_w1 && frac < opts.relax_z1) ||
                      (wnew <= opts.relax_w2 && frac < opts.relax_z2) || (frac < opts.relax_z3);
-        if (opts.max_width > 0 && wnew > opts.max_width) merge = false;
+        // no width cap here: a chain that merges without (much) fill is merged whole and then cut into blocks of
+        // exactly max_width columns below, so that the update kernel's 128x128 tiles are full in dense regions
         if (!merge) break;
         p.start = c.start;
         p.m = (int32_t)mnew;
@@ -336,12 +337,9 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     for (auto& s : out) {
       int32_t w = s.end - s.start;
       if (w <= opts.max_width) { sp.push_back(s); continue; }
-      int32_t nparts = (w + opts.max_width - 1) / opts.max_width;
-      int32_t base = w / nparts, rem = w % nparts, st = s.start;
-      for (int32_t p = 0; p < nparts; ++p) {
-        int32_t ww = base + (p < rem ? 1 : 0);
+      for (int32_t st = s.start; st < s.end; st += opts.max_width) {
+        const int32_t ww = std::min<int32_t>(opts.max_width, s.end - st);
         sp.push_back(SN{st, st + ww, s.m - (st - s.start), 0});
-        st += ww;
       }
     }
     out.swap(sp);
