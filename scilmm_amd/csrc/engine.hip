@@ -76,7 +76,7 @@ struct Dev {
   std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
   int ablate = 0;
-  int update_variant = 1;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
+  int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   std::vector<hipEvent_t> pev;     // 4 events per level when profiling
 };
@@ -1120,3 +1120,14 @@ int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on) {
 const char* scilmm_version(void) { return "scilmm_hip 0.1 (gfx950)"; }
 
 }  // extern "C"
+
+#ifdef SCILMM_POTRF_PROF
+extern "C" int scilmm_debug_potrf_prof(unsigned long long* out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(scilmm::g_potrf_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(scilmm::g_potrf_prof), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif

@@ -278,9 +278,9 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
     const int64_t md = dn.md;
     if (ABL == 2) {
 #pragma unroll
-      for (int i = 0; i < KC / KA; ++i) ra[i] = 1.0e-3;
+      for (int i = 0; i < KC / KA; ++i) ra[i] = 0.0;
 #pragma unroll
-      for (int i = 0; i < KC / KB; ++i) rb[i] = 1.0e-3;
+      for (int i = 0; i < KC / KB; ++i) rb[i] = 0.0;
       return;
     }
     if (ipn >= 0) {
@@ -743,6 +743,19 @@ __global__ __launch_bounds__(128) void k_reduce(DevSym S, const int32_t* __restr
 // Blocked by 16: the 16 x 16 diagonal blocks are factored and inverted by ONE wave in registers with
 // cross-lane shuffles (no barriers); panel solve, trailing update and the block recursion for the
 // inverse run on all 256 threads out of LDS.  ~30 barriers instead of ~200 + a 2000-step serial loop.
+// value of x in lane `src` (wave-uniform src) as a scalar broadcast: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double bc_lane(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+
+#ifdef SCILMM_POTRF_PROF
+__device__ unsigned long long g_potrf_prof[16];
+#define PPROF(i) do { if (w == NB && tid == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_potrf_prof[i], t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define PPROF(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                double* __restrict__ invD, double* __restrict__ logd,
                                                int32_t* __restrict__ status) {
@@ -759,44 +772,63 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   double* P = L + S.sn_loff[s];
   const int nb = (w + 15) >> 4, W = nb << 4;  // padded with an identity block
+#ifdef SCILMM_POTRF_PROF
+  unsigned long long tprev_ = wall_clock64();
+  if (w == NB && tid == 0) atomicAdd(&g_potrf_prof[15], 1ull);
+#endif
 #define XINV(r, c) ((r) > (c) ? T[(c) * LD + (r)] : ((r) == (c) ? xd[(r)] : 0.0))
-  for (int idx = tid; idx < W * W; idx += 256) {
-    const int k = idx / W, i = idx - k * W;
-    double v = (i == k) ? 1.0 : 0.0;
-    if (i < w && k < w) v = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
-    T[i * LD + k] = v;
+  // lower triangle of the block -> LDS, eight loads in flight per thread (the strict upper part starts as zero)
+  for (int base = tid; base < W * W; base += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u;
+      const int k = idx / W, i = idx - k * W;
+      v[u] = (i == k) ? 1.0 : 0.0;
+      if (idx < W * W && i < w && k < w) v[u] = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u;
+      const int k = idx / W, i = idx - k * W;
+      if (idx < W * W) T[i * LD + k] = v[u];
+    }
   }
   if (tid < NB) xd[tid] = 1.0;
   __syncthreads();
+  PPROF(0);
   for (int kb = 0; kb < nb; ++kb) {
     const int o = kb << 4;
     if (wv == 0) {
-      // ---- 16 x 16 diagonal block in registers: lane r (mod 16) owns row r
+      // ---- 16 x 16 diagonal block in registers, right-looking: lane r (mod 16) owns row r of L; the pivot
+      //      column is broadcast with v_readlane (scalar operands), so a step is one rsqrt + independent FMAs
       const int r = lane & 15;
-      double a[16], x[16];
+      double a[16], x[16], rs[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? T[(o + r) * LD + o + c] : 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double v = a[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v -= a[k] * __shfl(a[k], j, 16);
-        double dj = __shfl(v, j, 16);
+        double dj = bc_lane(a[j], j);
         if (!(dj > 0.0) || !(dj < 1.0e300)) {
           if (lane == 0) atomicMin(status, c0 + o + j);
           dj = 1.0;
         }
-        const double sd = sqrt(dj);
-        a[j] = (r == j) ? sd : ((r > j) ? v / sd : 0.0);
+        double y = rsqrt(dj);
+        y = y * (1.5 - 0.5 * dj * y * y);  // one Newton step: full double precision
+        rs[j] = y;
+        const double lj = (r >= j) ? a[j] * y : 0.0;  // L(r, j); the diagonal comes out as dj / sqrt(dj)
+        a[j] = lj;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] -= lj * bc_lane(lj, c);  // A(r,c) -= L(r,j) L(c,j)  (used for r >= c)
       }
-      // inverse of the block: lane r owns COLUMN r of the inverse
+      // inverse of the block by forward substitution, right-looking: lane r owns COLUMN r of X = L^-1
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = (i == r) ? 1.0 : 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double sum = (r == j) ? 1.0 : 0.0;
+        x[j] *= rs[j];  // rows above the diagonal stay exactly zero
 #pragma unroll
-        for (int k = 0; k < j; ++k) sum -= __shfl(a[k], j, 16) * x[k];
-        const double djj = __shfl(a[j], j, 16);
-        x[j] = (j >= r) ? sum / djj : 0.0;
+        for (int i = j + 1; i < 16; ++i) x[i] -= bc_lane(a[j], i) * x[j];  // L(i, j) = a[j] in lane i
       }
       if (lane < 16) {
 #pragma unroll
@@ -808,6 +840,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       }
     }
     __syncthreads();
+    PPROF(1);
     const int nrem = W - o - 16;
     if (nrem > 0) {
       const int nbr = nrem >> 4;
@@ -828,6 +861,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
         for (int r = 0; r < 4; ++r) T[(r0 + lk + 4 * r) * LD + o + li] = acc[r];
       }
       __syncthreads();
+      PPROF(2);
       // ---- trailing update, lower block pairs (ib >= kk): C_{ib,kk} -= B_ib * B_kk^T (MFMA)
       int pidx = 0;
       for (int ib = 0; ib < nbr; ++ib)
@@ -848,6 +882,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
           }
         }
       __syncthreads();
+      PPROF(3);
     }
   }
   // ---- inverse of the whole block by block sub-diagonals: X_ij = -X_ii * sum_{kb=j}^{i-1} L_{i,kb} X_{kb,j}
@@ -888,10 +923,17 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     }
     __syncthreads();
   }
-  if (tid == 64) {
-    double sl = 0.0;
-    for (int j = 0; j < w; ++j) sl += log(T[j * LD + j]);
-    logd[s] = sl;
+  PPROF(4);
+  {
+    // sum(log diag): one log per thread, wave reduction, fixed summation order
+    __shared__ double lgp[4];
+    double lg = 0.0;
+    for (int j = tid; j < w; j += 256) lg += log(T[j * LD + j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off, 64);
+    if (lane == 0) lgp[wv] = lg;
+    __syncthreads();
+    if (tid == 0) logd[s] = (lgp[0] + lgp[1]) + (lgp[2] + lgp[3]);
   }
   double* I = invD + S.inv_off[s];
   for (int idx = tid; idx < w * w; idx += 256) {
@@ -899,6 +941,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     P[(int64_t)k * m + i] = (i >= k) ? T[i * LD + k] : 0.0;
     I[k * w + i] = XINV(i, k);
   }
+  PPROF(5);
 #undef XINV
 }
 
