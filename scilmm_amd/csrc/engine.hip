@@ -78,6 +78,20 @@ struct Dev {
   int ablate = 0;
   int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
+  // dense-chain sweeps (k_chain): the last chain_T levels are single fronts whose mutual update pairs are contiguous
+  int32_t chain_T = 0, chain_l0 = 0;
+  int32_t* d_chain = nullptr;
+  int32_t* d_colmap = nullptr;     // forward: column -> row maps of the non-contiguous chain pairs
+  int32_t* d_cf_ptr = nullptr;     // forward: pairs of chain target i (descendants ascending)
+  ChainPair* d_cf = nullptr;
+  int32_t* d_cb_ptr = nullptr;     // backward: pairs of chain descendant i (targets descending)
+  ChainPair* d_cb = nullptr;
+  int64_t* d_cg_ptr = nullptr;     // backward: pairs (chain target, non-chain descendant) grouped by descendant
+  int32_t* d_cg_pairs = nullptr;
+  int64_t chain_groups = 0;
+  int32_t* d_chain_flags = nullptr;  // [chain_T * RPMAX/CW] epoch stamps
+  int32_t* d_chain_err = nullptr;
+  int32_t chain_epoch = 0;
   std::vector<hipEvent_t> pev;     // 4 events per level when profiling
 };
 
@@ -463,6 +477,106 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->allocs.push_back(sc);
     D->scratch = (double*)sc;
   }
+  // ---- dense-chain plan for the triangular sweeps
+  {
+    const int32_t ns = S.nsuper;
+    // the sweep set: all fronts of the top levels, as many levels as fit the cap (the dense chain and the few
+    // wide fronts just below it; every dependency of a member is either a member or finished by the level kernels)
+    // (a level joins while it has at most `wide` fronts: a pull step costs ~8 us whatever its size, so the many
+    // small fronts of the lower levels stay with the level kernels -- measured optimum at the 100k pedigree)
+    const char* ecap = getenv("SCILMM_CHAIN_CAP");
+    const char* ewide = getenv("SCILMM_CHAIN_WIDE");
+    const int32_t cap = ecap ? atoi(ecap) : 2048, wide = ewide ? atoi(ewide) : 12;
+    int32_t l0 = S.nlevels;
+    while (l0 > 0 && S.level_ptr[l0] - S.level_ptr[l0 - 1] <= wide && S.level_ptr[S.nlevels] - S.level_ptr[l0 - 1] <= cap) --l0;
+    const char* enc = getenv("SCILMM_NO_CHAIN");
+    int32_t T = l0 < S.nlevels ? S.level_ptr[S.nlevels] - S.level_ptr[l0] : 0;
+    if (S.nlevels - l0 < 4 || (enc && enc[0] == '1')) T = 0;
+    D->chain_T = T;
+    D->chain_l0 = l0;
+    if (T > 0) {
+      std::vector<int32_t> chain(T), pos(ns, -1);
+      for (int32_t i = 0; i < T; ++i) {
+        chain[i] = S.level_fronts[S.level_ptr[l0] + i];  // level order = a topological order of the update pairs
+        pos[chain[i]] = i;
+      }
+      std::vector<std::vector<ChainPair>> fw(T), bw(T);
+      std::vector<int32_t> colmap;  // forward, non-contiguous pairs: target column -> row of the pair (or -1)
+      std::vector<std::pair<int32_t, int32_t>> outside;  // (descendant, pair id): chain target, descendant below the chain
+      for (int32_t i = 0; i < T; ++i) {
+        const int32_t t = chain[i];
+        for (int64_t e = S.upd_ptr[t]; e < S.upd_ptr[t + 1]; ++e) {
+          const int32_t d = S.upd_src[e];
+          if (pos[d] >= 0) {
+            int32_t moff = 0;
+            if (S.upd_jp0[e] < 0) {
+              moff = (int32_t)colmap.size();
+              colmap.resize(colmap.size() + NB, -1);
+              const int32_t* rd = S.sn_rows.data() + S.sn_rowptr[d];
+              for (int32_t q = S.upd_p0[e]; q < S.upd_p1[e]; ++q) colmap[(size_t)moff + (rd[q] - S.sn_start[t])] = q - S.upd_p0[e];
+            }
+            fw[i].push_back(ChainPair{pos[d], S.upd_p0[e], S.upd_p1[e] - S.upd_p0[e], S.upd_jp0[e], moff});
+            bw[pos[d]].push_back(ChainPair{i, S.upd_p0[e], S.upd_p1[e] - S.upd_p0[e], S.upd_jp0[e], 0});
+          } else {
+            outside.push_back({d, (int32_t)e});
+          }
+        }
+      }
+      std::vector<int32_t> fptr(T + 1, 0), bptr(T + 1, 0);
+      std::vector<ChainPair> fl, bl;
+      for (int32_t i = 0; i < T; ++i) {
+        std::sort(fw[i].begin(), fw[i].end(), [](const ChainPair& a, const ChainPair& b) { return a.other < b.other; });
+        std::sort(bw[i].begin(), bw[i].end(), [](const ChainPair& a, const ChainPair& b) { return a.other > b.other; });
+        fl.insert(fl.end(), fw[i].begin(), fw[i].end());
+        bl.insert(bl.end(), bw[i].begin(), bw[i].end());
+        fptr[i + 1] = (int32_t)fl.size();
+        bptr[i + 1] = (int32_t)bl.size();
+      }
+      // group by descendant, order by first row, merge adjacent row ranges (rows of consecutive chain blocks)
+      std::sort(outside.begin(), outside.end(), [&](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
+        if (a.first != b.first) return a.first < b.first;
+        return S.upd_p0[a.second] < S.upd_p0[b.second];
+      });
+      std::vector<int64_t> gptr;
+      std::vector<int32_t> gpairs;  // triples (descendant, p0, p1)
+      for (size_t k = 0; k < outside.size(); ++k) {
+        const int32_t d = outside[k].first, e = outside[k].second;
+        const bool newgrp = k == 0 || d != outside[k - 1].first;
+        if (newgrp) gptr.push_back((int64_t)gpairs.size() / 3);
+        if (!newgrp && gpairs.back() == S.upd_p0[e]) {
+          gpairs.back() = S.upd_p1[e];
+        } else {
+          gpairs.push_back(d);
+          gpairs.push_back(S.upd_p0[e]);
+          gpairs.push_back(S.upd_p1[e]);
+        }
+      }
+      D->chain_groups = (int64_t)gptr.size();
+      gptr.push_back((int64_t)gpairs.size() / 3);
+      const int32_t* t32; const int64_t* t64; const ChainPair* tcp;
+      if (fl.empty()) fl.push_back(ChainPair{0, 0, 0, 0, 0});
+      if (bl.empty()) bl.push_back(ChainPair{0, 0, 0, 0, 0});
+      if (colmap.empty()) colmap.push_back(-1);
+      if ((st = upload(sym, D, colmap, &t32)) != SCILMM_OK) return st; D->d_colmap = (int32_t*)t32;
+      if (gpairs.empty()) gpairs.assign(3, 0);
+      const int64_t n_ranges = (int64_t)gpairs.size() / 3;
+      if ((st = upload(sym, D, chain, &t32)) != SCILMM_OK) return st; D->d_chain = (int32_t*)t32;
+      if ((st = upload(sym, D, fptr, &t32)) != SCILMM_OK) return st; D->d_cf_ptr = (int32_t*)t32;
+      if ((st = upload(sym, D, bptr, &t32)) != SCILMM_OK) return st; D->d_cb_ptr = (int32_t*)t32;
+      if ((st = upload(sym, D, fl, &tcp)) != SCILMM_OK) return st; D->d_cf = (ChainPair*)tcp;
+      if ((st = upload(sym, D, bl, &tcp)) != SCILMM_OK) return st; D->d_cb = (ChainPair*)tcp;
+      if ((st = upload(sym, D, gptr, &t64)) != SCILMM_OK) return st; D->d_cg_ptr = (int64_t*)t64;
+      if ((st = upload(sym, D, gpairs, &t32)) != SCILMM_OK) return st; D->d_cg_pairs = (int32_t*)t32;
+      std::vector<int32_t> zeros((size_t)T * (RPMAX / CW) + 1, 0);
+      if ((st = upload(sym, D, zeros, &t32)) != SCILMM_OK) return st;
+      D->d_chain_flags = (int32_t*)t32;
+      D->d_chain_err = D->d_chain_flags + (size_t)T * (RPMAX / CW);
+      if (getenv("SCILMM_VERBOSE"))
+        fprintf(stderr, "[scilmm plan] chain sweep: %d fronts (levels %d..%d), %lld inner pairs (%lld column maps), %lld outside pairs in %lld groups\n",
+                T, l0, S.nlevels - 1, (long long)fl.size(), (long long)(colmap.size() / NB), (long long)outside.size(), (long long)D->chain_groups);
+      (void)n_ranges;
+    }
+  }
   *out = D;
   return SCILMM_OK;
 }
@@ -764,7 +878,8 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     const unsigned pb = (unsigned)((tot + 255) / 256);
     if (mode == 0) {
       hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dB, D->W);
-      for (int32_t l = 0; l < S.nlevels; ++l) {
+      const int32_t lend = D->chain_T > 0 ? D->chain_l0 : S.nlevels;  // the chain levels are swept by k_chain
+      for (int32_t l = 0; l < lend; ++l) {
         const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
         const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
         if (f1 == f0) continue;
@@ -790,11 +905,44 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
           hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
                              fac->L, (const double*)D->X, D->W, rp);
       }
+      if (D->chain_T > 0) {
+        const unsigned grid = (unsigned)D->chain_T * gy;
+        const int32_t ep = ++D->chain_epoch;
+        if (mf)
+          hipLaunchKernelGGL((k_chain<true, false>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
+                             (const int32_t*)D->d_cf_ptr, (const ChainPair*)D->d_cf, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+        else
+          hipLaunchKernelGGL((k_chain<false, false>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
+                             (const int32_t*)D->d_cf_ptr, (const ChainPair*)D->d_cf, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+      }
       if (!mid_recorded) {
         HIPCHK(hipEventRecord(D->ev[4], st));
         mid_recorded = true;
       }
-      for (int32_t l = S.nlevels - 1; l >= 0; --l) {
+      if (D->chain_T > 0) {
+        const unsigned grid = (unsigned)D->chain_T * gy;
+        const int32_t ep = ++D->chain_epoch;
+        if (mf)
+          hipLaunchKernelGGL((k_chain<true, true>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
+                             (const int32_t*)D->d_cb_ptr, (const ChainPair*)D->d_cb, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+        else
+          hipLaunchKernelGGL((k_chain<false, true>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
+                             (const int32_t*)D->d_cb_ptr, (const ChainPair*)D->d_cb, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+        // descendants below the chain: all their chain targets are final now, one read-modify-write each
+        if (D->chain_groups > 0) {
+          if (mf)
+            hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)D->chain_groups, gy), dim3(256), 0, st, D->v,
+                               (const int32_t*)D->d_cg_pairs, (const int64_t*)D->d_cg_ptr, fac->L, D->X, rp);
+          else
+            hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)D->chain_groups, gy), dim3(256), 0, st, D->v,
+                               (const int32_t*)D->d_cg_pairs, (const int64_t*)D->d_cg_ptr, fac->L, D->X, rp);
+        }
+      }
+      for (int32_t l = lend - 1; l >= 0; --l) {
         const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
         const int64_t p0 = S.level_pair_ptr[l], p1 = S.level_pair_ptr[l + 1];
         if (f1 > f0) {
@@ -808,10 +956,10 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         if (p1 > p0) {
           if (mf)
             hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
-                               fac->L, D->X, rp);
+                               (const int64_t*)nullptr, fac->L, D->X, rp);
           else
             hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
-                               fac->L, D->X, rp);
+                               (const int64_t*)nullptr, fac->L, D->X, rp);
         }
       }
       hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
@@ -839,6 +987,15 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
 
 int finish_rhs_timing(scilmm_symbolic* sym, Dev* D, int mode) {
   D->rhs_pending = -1;
+  if (D->chain_T > 0 && mode == 0) {
+    int32_t cerr = 0;
+    HIPCHK(hipMemcpy(&cerr, D->d_chain_err, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (cerr != 0) {
+      HIPCHK(hipMemset(D->d_chain_err, 0, sizeof(int32_t)));
+      sym->err = "chain sweep: a workgroup timed out waiting for its predecessor";
+      return SCILMM_ERR_DEVICE;
+    }
+  }
   float a = 0, b = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[3], D->ev[4]));
   HIPCHK(hipEventElapsedTime(&b, D->ev[4], D->ev[5]));
@@ -928,8 +1085,15 @@ int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor**
   scilmm_factor* f = new scilmm_factor();
   f->sym = sym;
   *out = f;
-  HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * (size_t)std::max<int64_t>(S.nnzL_stored, 1)));
-  HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * (size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1)));
+  // slack behind both arrays: the chain sweeps read whole 4-deep k-steps of a panel / an inverse block and
+  // discard the lanes past its last column (at most 3 columns of the tallest panel resp. of an NB-wide block)
+  int64_t max_m = 0;
+  for (int32_t q = 0; q < S.nsuper; ++q) max_m = std::max<int64_t>(max_m, S.sn_rowptr[q + 1] - S.sn_rowptr[q]);
+  const size_t padL = (size_t)(4 * max_m + 4 * NB), padI = (size_t)(5 * NB);
+  HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * ((size_t)std::max<int64_t>(S.nnzL_stored, 1) + padL)));
+  HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * ((size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1) + padI)));
+  HIPCHK(hipMemset(f->L + (size_t)std::max<int64_t>(S.nnzL_stored, 1), 0, sizeof(double) * padL));
+  HIPCHK(hipMemset(f->invD + (size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1), 0, sizeof(double) * padI));
   HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
   HIPCHK(hipMalloc((void**)&f->status, sizeof(int32_t)));
   return run_factorize(f, sigma2, bad_col);

@@ -1205,15 +1205,21 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
 // read-modify-write of X[cols of d] is exclusive: plain loads/stores, bitwise reproducible.
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __restrict__ pairs,
-                                                  const double* __restrict__ L, double* __restrict__ X, int32_t rp) {
+                                                  const int64_t* __restrict__ grp_ptr, const double* __restrict__ L,
+                                                  double* __restrict__ X, int32_t rp) {
+  // grp_ptr == nullptr: one update pair per workgroup.  Otherwise `pairs` holds triples (descendant, p0, p1) and
+  // workgroup b folds the row ranges [grp_ptr[b], grp_ptr[b+1]) -- all of the SAME descendant d -- into one
+  // read-modify-write of X[cols of d] (used after the chain sweep, where the targets of many levels are final at
+  // once: the rows of d that belong to consecutive chain blocks are merged into long ranges by the host).
   __shared__ __attribute__((aligned(16))) double Ps[NB * LDP];  // Ps[k*LDP + q] = L_d[p0+q0+q][k]
   __shared__ __attribute__((aligned(16))) double Xg[32 * LDW];  // gathered X rows, [q][c]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int c_lo = blockIdx.y * CW;
   const int rpl = min(CW, rp - c_lo);
   if (rpl <= 0) return;
-  const int32_t e = pairs[blockIdx.x];
-  const int32_t d = S.upd_src[e], p0 = S.upd_p0[e], p1 = S.upd_p1[e];
+  const int64_t g0 = grp_ptr ? grp_ptr[blockIdx.x] : (int64_t)blockIdx.x;
+  const int64_t g1 = grp_ptr ? grp_ptr[blockIdx.x + 1] : (int64_t)blockIdx.x + 1;
+  const int32_t d = grp_ptr ? pairs[3 * g0] : S.upd_src[pairs[g0]];
   const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
   const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
   const int32_t cd = S.sn_start[d], wd = S.sn_start[d + 1] - cd;
@@ -1225,10 +1231,13 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
   for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int cn = 0; cn < NCT; ++cn) acc[h][cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int64_t gi = g0; gi < g1; ++gi) {
+  const int32_t p0 = grp_ptr ? pairs[3 * gi + 1] : S.upd_p0[pairs[gi]];
+  const int32_t p1 = grp_ptr ? pairs[3 * gi + 2] : S.upd_p1[pairs[gi]];
   for (int32_t q0 = p0; q0 < p1; q0 += 32) {
     const int qn = min(32, p1 - q0);
     const int qn4 = (qn + 3) & ~3;
-    if (q0 > p0) __syncthreads();
+    if (q0 > p0 || gi > g0) __syncthreads();
     {
       const int q = tid & 31;
       for (int k = tid >> 5; k < NB; k += 8)
@@ -1264,6 +1273,7 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
       }
     }
   }
+  }
   {
     const int li = lane & 15, lr = lane >> 4;
 #pragma unroll
@@ -1281,6 +1291,290 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
       }
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Dense-chain sweeps.  The last levels of the elimination tree are a chain of single fronts (the blocks of
+// the trailing dense clique): level-by-level kernels spend ~170 us per block there, almost all of it latency.
+// These two kernels run the whole chain in ONE launch each: workgroup (chain block i, RHS window c) PULLS the
+// contributions of the other chain blocks as soon as they are final,
+//     forward :  x_i = invL_i   (w_i - sum_{j<i} L_ij   x_j)      L_ij  = rows [p0,p0+nq) of panel j
+//     backward:  x_i = invL_i^T (y_i - sum_{t>i} L_ti^T x_t)      L_ti  = rows [p0,p0+nq) of panel i
+// and publishes x_i through a flag (flag value = epoch of this launch, so flags are never reset).  The XCDs'
+// L2s are not coherent with each other, and device-scope fences (L2 write-back / invalidate) cost tens of
+// microseconds per step; instead only the communicated data is accessed coherently: x windows and flags are
+// written with agent-scope (write-through) stores and read with agent-scope (cache-bypassing) loads, the
+// producer drains its stores (s_waitcnt vmcnt(0)) before the barrier that precedes the flag store, and the
+// panels of L keep using ordinary cached loads.
+// A workgroup only ever waits for workgroups with a LOWER linear id, which the dispatcher starts first, so
+// the grid needs no co-residency guarantee; the wait is bounded (err flag) so every wave always exits.
+// The L fragments are read straight from global memory into the MFMA A operand BEFORE the wait: only the
+// 128 x 32 x-window of the block just finished is on the critical path.
+struct ChainPair {
+  int32_t other;  // chain position of the other block (descendant j forward, target t backward)
+  int32_t p0, nq; // rows [p0, p0+nq) of the descendant panel ...
+  int32_t jp0;    // ... are columns jp0.. of the target block when >= 0 (contiguous: every pair of a dense chain)
+  int32_t map;    // jp0 < 0, forward: offset into the column -> row map (NB entries, -1 = no such row)
+};
+
+// a wave-uniform pointer / integer moved to scalar registers (lets loads use the SGPR-base + 32-bit lane offset form)
+__device__ __forceinline__ int64_t uniform_i64(int64_t x) {
+  const uint64_t v = (uint64_t)x;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// element at byte offset voff8 (32-bit, per lane) from a wave-uniform base: SGPR base + VGPR offset addressing
+__device__ __forceinline__ double ld_off(const double* base, uint32_t voff8) {
+  return *(const double*)((const char*)base + voff8);
+}
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ bool chain_wait(const int32_t* flag, int32_t epoch, int32_t* err) {
+  // one thread spins; returns false on timeout / earlier error (the caller then leaves quietly)
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023) == 0) {
+      if (spins > (1 << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+#ifndef SCILMM_CHAIN_WAVES
+#define SCILMM_CHAIN_WAVES 2
+#endif
+template <bool MFMA, bool BWD>
+__global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int32_t T, const int32_t* __restrict__ chain,
+                                               const int32_t* __restrict__ pair_ptr, const ChainPair* __restrict__ pairs,
+                                               const int32_t* __restrict__ colmap, const double* __restrict__ L,
+                                               const double* __restrict__ invD, const double* W, double* X, int32_t rp,
+                                               int32_t ncw, int32_t* flags, int32_t epoch, int32_t* err) {
+  __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // x window of the other block, then w_i: [k][c]
+  __shared__ int s_ok, s_ready;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int32_t lin = blockIdx.x;
+  const int32_t ord = lin / ncw, c = lin - ord * ncw;
+  const int32_t i = BWD ? T - 1 - ord : ord;
+  const int c_lo = c * CW;
+  const int rpl = min(CW, rp - c_lo);
+  const int ncn = rpl >> 4;
+  const int32_t s = chain[i];
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const double* I = invD + S.inv_off[s];
+  constexpr int NK = NB / 4;
+  // wave wv owns row block wv of the result (rows / columns 16 wv .. 16 wv + 15 of block i)
+  const int jrow = 16 * wv + li;  // A-operand row of this lane
+  const int32_t e0 = pair_ptr[i], e1 = pair_ptr[i + 1];
+  // ---- how many leading pairs are already final?  one parallel look at their flags instead of one round trip each
+  if (wv == 0) {
+    int ready = 0;
+    bool open = true;
+    for (int32_t base = e0; base < e1 && open; base += 64) {
+      bool r = false;
+      if (base + lane < e1)
+        r = __hip_atomic_load(flags + (int64_t)pairs[base + lane].other * ncw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+      const unsigned long long b = __ballot(r);
+      const int lead = (~b == 0ull) ? 64 : __builtin_ctzll(~b);
+      ready += lead;
+      open = lead == 64;
+    }
+    if (lane == 0) s_ready = ready;
+  }
+  // ---- everything of the diagonal step that does not depend on other blocks: op(invL_i) fragment and own rows
+  const int w4 = (w + 3) & ~3;
+  const int kbeg = BWD ? 16 * wv : 0;
+  const int kend = BWD ? w4 : min(w4, 16 * (wv + 1));
+  double iv[NK];
+  // Fragment loads use a wave-uniform base (SGPR pair) per k-step plus ONE 32-bit lane offset, whole k-steps
+  // are loaded or skipped by a uniform test, and lanes past the last column / row are discarded afterwards (the
+  // arrays carry slack for that): no per-load address registers, no per-lane branches.
+  auto load_iv = [&]() {
+    const int jc = jrow < w ? jrow : 0;
+    const uint32_t voff = (uint32_t)(BWD ? jc * w + lk : lk * w + jc);
+    const int klast = uniform_int(max(w4 - 4, 0)), wu = uniform_int(w);
+    const double* Ib = invD + uniform_i64(S.inv_off[s]);
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {  // unconditional, independent loads (a k-step past the block re-reads the last one)
+      const int ku = min(4 * u, klast);
+      iv[u] = ld_off(Ib + (BWD ? ku : ku * wu), voff * 8u);
+    }
+  };  // (lanes / k-steps outside the triangle are masked where iv is used)
+  const double* Yin = BWD ? (const double*)X : W;
+  double yv[NCT][4];
+#pragma unroll
+  for (int cn = 0; cn < NCT; ++cn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jr = 16 * wv + lk + 4 * r;
+      yv[cn][r] = (jr < w && cn < ncn) ? Yin[(int64_t)(c0 + jr) * rp + c_lo + 16 * cn + li] : 0.0;
+    }
+  d4 acc[NCT];
+#pragma unroll
+  for (int cn = 0; cn < NCT; ++cn) acc[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+  __syncthreads();
+  const int32_t nready = s_ready;
+  bool ok = true;
+  // L fragment of pair e -> registers (independent of every flag): issued one pair ahead of its use
+  auto load_frag = [&](int32_t e, double (&av)[NK]) {
+    const ChainPair pr = pairs[e];
+    if (!BWD) {
+      // A[jrow][k] = L_ij[jrow][k] = P_j[k * md + p0 + q(jrow)],  k < w_j
+      const int32_t so = chain[pr.other];
+      const int32_t wo = S.sn_start[so + 1] - S.sn_start[so];
+      const int64_t md = S.sn_rowptr[so + 1] - S.sn_rowptr[so];
+      int q = jrow - pr.jp0;
+      if (pr.jp0 < 0) q = colmap[pr.map + jrow];
+      const bool rowok = q >= 0 && q < pr.nq;
+      const double* Pj = L + uniform_i64(S.sn_loff[so] + pr.p0);
+      const int64_t mdu = uniform_int((int)md);
+      const uint32_t voff = (uint32_t)(lk * (int)md + (rowok ? q : 0));
+      const int klast = uniform_int(max(((wo + 3) & ~3) - 4, 0));
+#pragma unroll
+      for (int u = 0; u < NK; ++u) av[u] = ld_off(Pj + (int64_t)min(4 * u, klast) * mdu, voff * 8u);
+    } else {
+      // A[jrow][q] = L_ti[q][jrow] = P_i[jrow * m + p0 + q],  q < nq
+      const double* Pi = L + uniform_i64(S.sn_loff[s] + pr.p0);
+      const uint32_t voff = (uint32_t)((jrow < w ? jrow : 0) * m + lk);
+      const int klast = uniform_int(max(((pr.nq + 3) & ~3) - 4, 0));
+#pragma unroll
+      for (int u = 0; u < NK; ++u) av[u] = ld_off(Pi + min(4 * u, klast), voff * 8u);
+    }
+  };
+  auto consume = [&](int32_t e, double (&av)[NK]) {
+    const ChainPair pr = pairs[e];
+    const int32_t so = chain[pr.other];
+    const int32_t co = S.sn_start[so], wo = S.sn_start[so + 1] - co;
+    const int kn = BWD ? ((pr.nq + 3) & ~3) : ((wo + 3) & ~3);  // depth of the product (rounded up to 4)
+    // lanes whose row / k lies outside the pair were loaded from a clamped address: mask them at the point of use
+    bool rowok;
+    if (!BWD) {
+      int q = jrow - pr.jp0;
+      if (pr.jp0 < 0) q = colmap[pr.map + jrow];
+      rowok = q >= 0 && q < pr.nq;
+    } else {
+      rowok = jrow < w;
+    }
+    const int kvalid = BWD ? pr.nq : wo;
+    if (e == e1 - 1) load_iv();
+    if (e - e0 >= nready) {
+      if (tid == 0) s_ok = chain_wait(flags + (int64_t)pr.other * ncw + c, epoch, err) ? 1 : 0;
+      __syncthreads();
+      ok = s_ok != 0;
+    }
+    if (ok) {
+      // x rows: forward = all columns of block j; backward = the rows of this pair (columns of block t).
+      // Plain (cached) loads are safe: nothing read x of that block on this CU / XCD before its flag was seen,
+      // and a 128-byte line never holds data of two producers (windows are 256-byte aligned).
+      const int nx = BWD ? pr.nq : wo;
+      const int cc = tid & 63;
+      if (cc < LDW)
+        for (int k = tid >> 6; k < kn; k += 8) {
+          double v = 0.0;
+          if (k < nx && cc < rpl) {
+            int64_t xr;
+            if (!BWD) xr = co + k;
+            else xr = (pr.jp0 >= 0) ? co + pr.jp0 + k : S.sn_rows[S.sn_rowptr[s] + pr.p0 + k];
+            v = X[xr * rp + c_lo + cc];
+          }
+          Ys[k * LDW + cc] = v;
+        }
+    }
+    __syncthreads();
+    if (ok) {
+      if (MFMA) {
+#pragma unroll
+        for (int u = 0; u < NK; ++u)
+          if (4 * u < kn) {
+#pragma unroll
+            for (int cn = 0; cn < NCT; ++cn)
+              if (cn < ncn)
+                acc[cn] = mfma_f64((rowok && 4 * u + lk < kvalid) ? av[u] : 0.0, Ys[(4 * u + lk) * LDW + 16 * cn + li], acc[cn]);
+          }
+      } else {
+        // scalar restatement in the same accumulator layout D[(l>>4)+4r][l&15]: A is re-read by (row, k)
+        for (int k = 0; k < kn; ++k) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int jr = 16 * wv + lk + 4 * r;
+            double a = 0.0;
+            if (!BWD) {
+              const int64_t md = S.sn_rowptr[so + 1] - S.sn_rowptr[so];
+              int q = jr - pr.jp0;
+              if (pr.jp0 < 0) q = colmap[pr.map + jr];
+              if (q >= 0 && q < pr.nq && k < wo) a = L[S.sn_loff[so] + (int64_t)k * md + pr.p0 + q];
+            } else {
+              if (jr < w && k < pr.nq) a = L[S.sn_loff[s] + (int64_t)jr * m + pr.p0 + k];
+            }
+#pragma unroll
+            for (int cn = 0; cn < NCT; ++cn)
+              if (cn < ncn) acc[cn][r] += a * Ys[k * LDW + 16 * cn + li];
+          }
+        }
+      }
+    }
+    __syncthreads();  // Ys is reused by the next pair
+  };
+  if (e0 == e1) load_iv();
+  for (int32_t e = e0; e < e1 && ok; ++e) {
+    double av[NK];
+    load_frag(e, av);
+    consume(e, av);
+  }
+  // ---- diagonal step: v = (W or X)[block i] - acc  ->  Ys,   x_i = op(invL_i) v
+  if (ok) {
+#pragma unroll
+    for (int cn = 0; cn < NCT; ++cn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jr = 16 * wv + lk + 4 * r;
+        if (jr < w4) Ys[jr * LDW + 16 * cn + li] = (jr < w && cn < ncn) ? yv[cn][r] - acc[cn][r] : 0.0;
+      }
+  }
+  __syncthreads();
+  if (ok && 16 * wv < w) {
+    d4 xa[NCT];
+#pragma unroll
+    for (int cn = 0; cn < NCT; ++cn) xa[cn] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (MFMA) {
+#pragma unroll
+      for (int u = 0; u < NK; ++u)
+        if (4 * u >= kbeg && 4 * u < kend) {
+#pragma unroll
+          for (int cn = 0; cn < NCT; ++cn)
+            if (cn < ncn)
+              xa[cn] = mfma_f64((jrow < w && 4 * u + lk < w) ? iv[u] : 0.0, Ys[(4 * u + lk) * LDW + 16 * cn + li], xa[cn]);
+        }
+    } else {
+      for (int k = kbeg; k < kend && k < w; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jr = 16 * wv + lk + 4 * r;
+          const double a = (jr < w) ? (BWD ? I[(int64_t)jr * w + k] : I[(int64_t)k * w + jr]) : 0.0;
+#pragma unroll
+          for (int cn = 0; cn < NCT; ++cn)
+            if (cn < ncn) xa[cn][r] += a * Ys[k * LDW + 16 * cn + li];
+        }
+    }
+#pragma unroll
+    for (int cn = 0; cn < NCT; ++cn)
+      if (cn < ncn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jr = 16 * wv + lk + 4 * r;
+          if (jr < w)
+            __hip_atomic_store(&X[(int64_t)(c0 + jr) * rp + c_lo + 16 * cn + li], xa[cn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
+  __syncthreads();
+  if (tid == 0 && ok) __hip_atomic_store(flags + (int64_t)i * ncw + c, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
