@@ -48,6 +48,12 @@ struct Dev {
   UpdWork* d_work_early = nullptr; // EARLY items (older descendants): side stream, overlaps the previous level
   std::vector<int64_t> early_ptr;  // [nlevels+1]
   int64_t max_slots = 0;           // partial slabs per scratch half (scratch is double-buffered by level parity)
+  // compact path (k_update_compact): sparse combos multiplied in their own coordinates, scattered into slabs
+  ComboDesc* d_ccombos = nullptr;
+  UpdWork* d_cwork = nullptr;      // late
+  UpdWork* d_cwork_early = nullptr;
+  std::vector<int64_t> cwork_ptr, cearly_ptr;  // [nlevels+1]
+  int64_t n_compact_combos = 0;
   hipStream_t side = nullptr;
   hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
   std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
@@ -245,6 +251,17 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
     const bool lookahead = !(ela && ela[0] == '1');
     std::vector<ComboDesc> late_tmp;
+    // compact combos, same early | late grouping per tile
+    // (each compact combo is cut at tile row TM/2: work item = (tile, half), which owns its cells exclusively)
+    std::vector<ComboDesc> ccd, ctmp[4];                     // ctmp: [half][late]
+    std::vector<int64_t> cptr((size_t)4 * ntiles0 + 1, 0);   // segment 4 g + 2 half + late
+    // Off by default: measured at the 100k pedigree it takes 10 ms out of the dense kernel (65 -> 55 ms) but the
+    // compact items of a level are few (two per tile) and latency-bound (~9 us per combo), so the level sequence
+    // gets longer (factorize 81 -> 98 ms).  Needs finer exclusive ownership or a pipelined item to pay off.
+    const char* enoc = getenv("SCILMM_COMPACT");
+    const bool allow_compact = enoc && enoc[0] == '1';
+    const char* ecf = getenv("SCILMM_COMPACT_FACTOR");
+    const double compact_factor = ecf ? atof(ecf) : 2.0;
     struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };
     std::vector<Cell> cells;
     cd.reserve((size_t)nc / 2 + 16);
@@ -281,7 +298,35 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         }
         if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
           // "late" = the descendant sits one level below the target (finished only just before this level)
-          if (!lookahead || S.sn_level[d] + 1 == S.sn_level[sfr]) late_tmp.push_back(x); else cd.push_back(x);
+          const bool late = !lookahead || S.sn_level[d] + 1 == S.sn_level[sfr];
+          // MFMA issue slots on the busiest SIMD: target coordinates (the 16 x 16 blocks inside the spans, eight
+          // waves) against compact coordinates (ceil(nt/16) x ceil(nq/16) blocks dealt to four waves, plus a
+          // fixed cost for the scatter): scattered rows make the spans wide although few blocks carry data
+          const int64_t ksteps = (x.wd + 3) / 4;
+          const int64_t njb = (x.jhi >> 4) - (x.jlo >> 4) + 1, nwv = (x.ihi >> 4) - (x.ilo >> 4) + 1;
+          const int64_t dense_slots = ksteps * njb * (nwv >= 5 ? 2 : 1);
+          const int64_t bt = (x.nt + 15) >> 4, bq = (x.nq + 15) >> 4;
+          const int64_t compact_slots = ksteps * ((bt * bq + 3) / 4) + 24;
+          if (allow_compact && bt * bq <= 16 && (double)compact_slots * compact_factor < (double)dense_slots) {
+            // first descendant row that lands at tile position >= TM/2
+            int32_t tsplit = x.nt;
+            if (R0 + TM / 2 < tile_end) {
+              const int32_t* rdx = S.sn_rows.data() + x.rowoff + x.ta;
+              tsplit = (int32_t)(std::lower_bound(rdx, rdx + x.nt, rs[R0 + TM / 2]) - rdx);
+            }
+            for (int h = 0; h < 2; ++h) {
+              ComboDesc y = x;
+              const int32_t t0 = h == 0 ? 0 : tsplit, t1 = h == 0 ? tsplit : x.nt;
+              if (t1 <= t0) continue;
+              y.ta = x.ta + t0;
+              y.nt = t1 - t0;
+              if (x.ip0 >= 0) y.ip0 = x.ip0 + t0;
+              ctmp[2 * h + (late ? 1 : 0)].push_back(y);
+            }
+            D->n_compact_combos++;
+          } else {
+            if (late) late_tmp.push_back(x); else cd.push_back(x);
+          }
           continue;
         }
         D->n_sparse_combos++;
@@ -301,8 +346,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       cd.insert(cd.end(), late_tmp.begin(), late_tmp.end());
       late_tmp.clear();
       dptr[g + 1] = (int64_t)cd.size();
+      for (int k4 = 0; k4 < 4; ++k4) {
+        ccd.insert(ccd.end(), ctmp[k4].begin(), ctmp[k4].end());
+        ctmp[k4].clear();
+        cptr[4 * g + k4 + 1] = (int64_t)ccd.size();
+      }
     }
     D->n_dense_combos = (int64_t)cd.size();
+
     D->n_cells = (int64_t)cells.size();
     std::sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) {
       if (a.late != b.late) return a.late < b.late;
@@ -357,8 +408,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         if ((st = upload(sym, D, wd_, &t32)) != SCILMM_OK) return st; CS.wd = (int32_t*)t32;
       }
       if (getenv("SCILMM_VERBOSE"))
-        fprintf(stderr, "[scilmm plan] dense combos %lld, cell-path combos %lld, cells %lld (early %lld) in %lld target groups\n",
-                (long long)D->n_dense_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
+        fprintf(stderr, "[scilmm plan] dense combos %lld, compact combos %lld, cell-path combos %lld, cells %lld (early %lld) in %lld target groups\n",
+                (long long)D->n_dense_combos, (long long)D->n_compact_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
                 (long long)ngroups_total);
       std::vector<Cell>().swap(cells);
     }
@@ -370,7 +421,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
     std::vector<int32_t> pslot_e(pslot.size(), 0), pnseg_e(pslot.size(), 0), red_tiles_e;
     D->red_ptr_e.assign(S.nlevels + 1, 0);
-    std::vector<UpdWork> work, work_early;
+    std::vector<UpdWork> work, work_early, cwork, cwork_early;
+    D->cwork_ptr.assign(S.nlevels + 1, 0);
+    D->cearly_ptr.assign(S.nlevels + 1, 0);
     D->work_ptr.assign(S.nlevels + 1, 0);
     D->early_ptr.assign(S.nlevels + 1, 0);
     D->red_ptr.assign(S.nlevels + 1, 0);
@@ -381,7 +434,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Each launch (the early
     // and the late part of a level) is cut into about 4 work items per CU of equal cost, so that one launch
     // fills the chip once with balanced items (late levels of a dense chain: few tiles, long combo lists).
-    auto combo_cost = [&](int64_t c) -> int64_t { return 1 + (cd[c].wd + KC - 1) / KC; };
+    auto combo_cost_d = [&](int64_t c) -> int64_t { return 1 + (cd[c].wd + KC - 1) / KC; };
+    auto combo_cost = [&](int64_t c) -> int64_t { return combo_cost_d(c); };
     const int64_t target_items = 1024, min_item = 24;
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -407,8 +461,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       int64_t total_e = 0, total_l = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
         const int32_t g = S.level_tiles[i];
-        for (int64_t c = dptr[g]; c < dmid[g]; ++c) total_e += combo_cost(c);
-        for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost(c);
+        for (int64_t c = dptr[g]; c < dmid[g]; ++c) total_e += combo_cost_d(c);
+        for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost_d(c);
       }
       const int64_t big = (int64_t)1 << 60;
       const int64_t per_e = allow_split ? std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items) : big;
@@ -419,8 +473,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         const size_t fe = work_early.size(), fl = work.size();
         const int64_t ne = cut(g, dptr[g], dmid[g], per_e, work_early);
         const int64_t nl = cut(g, dmid[g], dptr[g + 1], per_l, work);
-        // a single item of a launch subtracts straight into the panel (the early and the late launch of a
-        // level never overlap in time); two or more items of one launch go through partial slabs
+        // compact items: one per (tile, half, early | late); they run after the dense kernel and the reduce of
+        // the same launch sequence and own their cells, so they subtract straight into the panel
+        for (int h = 0; h < 2; ++h) {
+          if (cptr[4 * g + 2 * h + 1] > cptr[4 * g + 2 * h]) cwork_early.push_back(UpdWork{g, h, cptr[4 * g + 2 * h], cptr[4 * g + 2 * h + 1]});
+          if (cptr[4 * g + 2 * h + 2] > cptr[4 * g + 2 * h + 1]) cwork.push_back(UpdWork{g, h, cptr[4 * g + 2 * h + 1], cptr[4 * g + 2 * h + 2]});
+        }
+        // a single dense item of a launch subtracts straight into the panel (the early and the late launch of a
+        // level never overlap in time); two or more go through partial slabs
         const int64_t pe = ne >= 2 ? ne : 0, pl = nl >= 2 ? nl : 0;
         if (ne == 1) work_early[fe].slot = -1;
         if (nl == 1) work[fl].slot = -1;
@@ -444,10 +504,25 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->lev_cost_l.push_back(total_l);
       D->work_ptr[l + 1] = (int64_t)work.size();
       D->early_ptr[l + 1] = (int64_t)work_early.size();
+      D->cwork_ptr[l + 1] = (int64_t)cwork.size();
+      D->cearly_ptr[l + 1] = (int64_t)cwork_early.size();
       D->red_ptr[l + 1] = (int64_t)red_tiles.size();
       D->red_ptr_e[l + 1] = (int64_t)red_tiles_e.size();
     }
     D->max_slots = std::max<int64_t>(max_slots, 1);
+    {
+      if (ccd.empty()) ccd.push_back(ComboDesc{});
+      const ComboDesc* dcc;
+      if ((st = upload(sym, D, ccd, &dcc)) != SCILMM_OK) return st;
+      D->d_ccombos = (ComboDesc*)dcc;
+      if (cwork.empty()) cwork.push_back(UpdWork{0, 0, 0, 0});
+      if (cwork_early.empty()) cwork_early.push_back(UpdWork{0, 0, 0, 0});
+      const UpdWork* dcw;
+      if ((st = upload(sym, D, cwork, &dcw)) != SCILMM_OK) return st;
+      D->d_cwork = (UpdWork*)dcw;
+      if ((st = upload(sym, D, cwork_early, &dcw)) != SCILMM_OK) return st;
+      D->d_cwork_early = (UpdWork*)dcw;
+    }
     if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
     {
       const UpdWork* dwe;
@@ -704,6 +779,14 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     launches++;
   };
   const size_t half = (size_t)D->max_slots * TM * NB;
+  auto launch_compact = [&](hipStream_t stream, const UpdWork* cw, int64_t cnt) {
+    if (cnt <= 0) return;
+    if (D->use_mfma)
+      hipLaunchKernelGGL(k_update_compact<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L);
+    else
+      hipLaunchKernelGGL(k_update_compact<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L);
+    launches++;
+  };
   auto launch_cells = [&](hipStream_t stream, int which, int32_t l) {
     const Dev::CellSet& CS = D->cellset[which];
     const int64_t u0 = CS.level_ptr[l], u1 = CS.level_ptr[l + 1];
@@ -716,7 +799,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     launches++;
   };
   auto has_early = [&](int32_t l) -> bool {
-    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l];
+    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cearly_ptr[l + 1] > D->cearly_ptr[l] || D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l];
   };
   // Look-ahead: the EARLY part of level l+1 (descendants finished at levels <= l-1) runs on the side stream
   // while the main stream works through level l's latency-bound tail (late update, reduce, cells, potrf, trsm).
@@ -737,6 +820,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
         launches++;
       }
     }
+    launch_compact(sd, D->d_cwork_early + D->cearly_ptr[l], D->cearly_ptr[l + 1] - D->cearly_ptr[l]);
     launch_cells(sd, 0, l);  // early cells: same stream, after the early MFMA update of the same panels
     HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
     return SCILMM_OK;
@@ -765,6 +849,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
                          D->d_tile_pnseg, (const double*)sh, fac->L);
       launches++;
     }
+    launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
     launch_cells(st, 1, l);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
     if (f1 > f0) {

@@ -644,6 +644,129 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update2(DevSy
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compact path of the supernodal update: combos whose rows / columns are scattered over the target tile
+// (a family subtree updating a few dozen of the 128 x 128 cells' rows and columns) would keep all eight
+// waves and all column blocks of k_update busy although only ceil(nt/16) x ceil(nq/16) blocks carry data.
+// Here such a combo is multiplied in ITS OWN coordinates (rows ta.. and p0.. of the descendant, staged
+// contiguously), and the nt x nq result is subtracted from the panel cell by cell.  A work item owns one half
+// (64 rows) of a tile and runs after the dense update and its reduce on the same stream, so it is the only
+// writer of its cells; fixed order of its combos + one writer per cell per combo => bitwise reproducible (the L2
+// atomics of one combo are drained before the next one starts).
+constexpr int KCQ = 16;  // K depth per staging chunk of the compact path
+
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_update_compact(DevSym S, const UpdWork* __restrict__ work,
+                                                        const ComboDesc* __restrict__ combos, double* __restrict__ L) {
+  __shared__ __attribute__((aligned(16))) double As[KCQ * LDA];  // [k][t]  descendant rows of the tile (compact)
+  __shared__ __attribute__((aligned(16))) double Bs[KCQ * LDB];  // [k][q]  descendant rows = target columns (compact)
+  __shared__ int32_t rowlab[TM];
+  __shared__ int32_t pos[TM];   // compact row t -> tile position
+  __shared__ int32_t col[NB];   // compact column q -> target column
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const UpdWork wk = work[blockIdx.x];
+  const int32_t g = wk.tile;
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s];
+  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  double* Q = L + S.sn_loff[s] + R0;  // cell (tile position i, target column j) at Q[j * m + i]
+  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
+  __syncthreads();
+  for (int64_t c = wk.cb; c < wk.ce; ++c) {
+    const ComboDesc d = combos[c];
+    if (tid < d.nt) {
+      int p;
+      if (d.ip0 >= 0) {
+        p = d.ip0 + tid;
+      } else {
+        const int32_t lab = S.sn_rows[d.rowoff + d.ta + tid];
+        int lo = 0, hi = nrow;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
+        }
+        p = lo;
+      }
+      pos[tid] = p;
+    }
+    if (tid >= 128 && tid - 128 < d.nq) {
+      const int q = tid - 128;
+      col[q] = (d.jp0 >= 0) ? d.jp0 + q : S.sn_rows[d.rowoff + d.p0 + q] - c0;
+    }
+    const int bq = (d.nq + 15) >> 4;
+    const int nblk = ((d.nt + 15) >> 4) * bq;  // <= 16 by the host's classification
+    d4 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double* Pd = L + d.loff;
+    const int64_t md = d.md;
+    for (int k0 = 0; k0 < d.wd; k0 += KCQ) {
+      const int kc = min(KCQ, d.wd - k0);
+      const int kc4 = (kc + 3) & ~3;
+      __syncthreads();  // the previous chunk has been consumed
+      {
+        // 256 threads: thread (x = tid & 127, kk = tid >> 7) stages k = kk, kk + 2, ... of row x for A and for B
+        const int x = tid & 127, kk = tid >> 7;
+        const bool ha = x < d.nt, hb = x < d.nq;
+        const double* pa = Pd + (int64_t)(k0 + kk) * md + d.ta + (ha ? x : 0);
+        const double* pb = Pd + (int64_t)(k0 + kk) * md + d.p0 + (hb ? x : 0);
+        double va[KCQ / 2], vb[KCQ / 2];
+#pragma unroll
+        for (int i = 0; i < KCQ / 2; ++i) {
+          const int k = min(kk + 2 * i, kc - 1) - kk;  // clamped into the chunk: unconditional, independent loads
+          va[i] = pa[(int64_t)k * md];
+          vb[i] = pb[(int64_t)k * md];
+        }
+#pragma unroll
+        for (int i = 0; i < KCQ / 2; ++i) {
+          const int k = kk + 2 * i;
+          if (k < kc4) {
+            As[k * LDA + x] = (ha && k < kc) ? va[i] : 0.0;
+            Bs[k * LDB + x] = (hb && k < kc) ? vb[i] : 0.0;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int b = wv + 4 * a;
+        if (b < nblk) {
+          const int ib = b / bq, jb = b - ib * bq;
+          if (MFMA) {
+            for (int k4 = 0; k4 < kc4; k4 += 4)
+              acc[a] = mfma_f64(Bs[(k4 + lk) * LDB + 16 * jb + li], As[(k4 + lk) * LDA + 16 * ib + li], acc[a]);
+          } else {
+            for (int k = 0; k < kc4; ++k)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[a][r] += Bs[k * LDB + 16 * jb + lk + 4 * r] * As[k * LDA + 16 * ib + li];
+          }
+        }
+      }
+    }
+    // scatter: D[M = q][N = t] -> slab(col[q], pos[t]); one writer per cell within a combo
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int b = wv + 4 * a;
+      if (b < nblk) {
+        const int ib = b / bq, jb = b - ib * bq;
+        const int t = 16 * ib + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * jb + lk + 4 * r;
+          if (t < d.nt && q < d.nq) unsafeAtomicAdd(&Q[(int64_t)col[q] * m + pos[t]], -acc[a][r]);
+        }
+      }
+    }
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this combo's adds are complete before the next combo's
+    __syncthreads();                                       // (fixed summation order), and pos / col may be rewritten
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cell-wise path for the small update pairs (a few rows x a few columns of a narrow descendant): the host
 // groups every contributed target cell by address; one thread owns one target cell and subtracts the dot
 // products  sum_k L_d[t,k] L_d[q,k]  of all its contributions in a fixed order.  No LDS, no barriers, no

@@ -178,6 +178,24 @@ def test_factorization_is_bitwise_reproducible():
     assert np.array_equal(L1.data, L2.data) and np.array_equal(L1.indices, L2.indices)
 
 
+def test_compact_update_path_matches_oracle(monkeypatch):
+    """Opt-in compact update path (SCILMM_COMPACT=1): same factor as the oracle, and still no float-order races."""
+    from oracle import oracle as O
+    monkeypatch.setenv("SCILMM_COMPACT", "1")
+    A, _ = small_pedigree(10000, 0.01, 0)
+    n = A.shape[0]
+    sym = _engine([A, sp.identity(n, format="csr")])
+    f = sym.factorize([0.4, 0.6])
+    V = (0.4 * A + 0.6 * sp.identity(n)).tocsr()
+    of = O.OracleFactor(V, f.P())
+    assert abs(f.logdet() - of.logdet()) <= TOL * max(1.0, abs(of.logdet()))
+    L1 = f.L()
+    f.refactorize([0.4, 0.6])
+    assert np.array_equal(L1.data, f.L().data)
+    b = np.random.default_rng(1).standard_normal((n, 3))
+    assert np.abs(V @ f(b) - b).max() < 1e-9
+
+
 def test_full_size_properties_100k():
     """BASELINE config 2 (100k, sf 0.005) at full size through size-independent properties."""
     from scilmm_amd.harness.pedigree import make_problem
