@@ -82,6 +82,7 @@ struct Dev {
   std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
   int ablate = 0;
+  int look_depth = 2;      // "late" = descendants at most this many levels below the target; older ones are "early"
   int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   // dense-chain sweeps (k_chain): the last chain_T levels are single fronts whose mutual update pairs are contiguous
@@ -250,6 +251,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
     const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
     const bool lookahead = !(ela && ela[0] == '1');
+    {
+      const char* eld = getenv("SCILMM_LOOK_DEPTH");
+      D->look_depth = eld ? std::max(1, atoi(eld)) : 2;  // measured at 100k: depth 1 81.4 ms, 2 77.6 ms, 3 78.4 ms
+    }
+    const int32_t depth = D->look_depth;
     std::vector<ComboDesc> late_tmp;
     // compact combos, same early | late grouping per tile
     // (each compact combo is cut at tile row TM/2: work item = (tile, half), which owns its cells exclusively)
@@ -298,7 +304,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         }
         if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
           // "late" = the descendant sits one level below the target (finished only just before this level)
-          const bool late = !lookahead || S.sn_level[d] + 1 == S.sn_level[sfr];
+          const bool late = !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr];
           // MFMA issue slots on the busiest SIMD: target coordinates (the 16 x 16 blocks inside the spans, eight
           // waves) against compact coordinates (ceil(nt/16) x ceil(nq/16) blocks dealt to four waves, plus a
           // fixed cost for the scatter): scattered rows make the spans wide although few blocks carry data
@@ -338,7 +344,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
             const int64_t j = rd[q] - c0s;
             if (R < j) continue;  // strict upper part of the diagonal block is never referenced
             cells.push_back(Cell{S.sn_loff[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr],
-                                 (!lookahead || S.sn_level[d] + 1 == S.sn_level[sfr]) ? 1 : 0});
+                                 (!lookahead || S.sn_level[d] + depth >= S.sn_level[sfr]) ? 1 : 0});
           }
         }
       }
@@ -548,7 +554,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     if ((st = upload(sym, D, pnseg, &tmp)) != SCILMM_OK) return st;
     D->d_tile_pnseg = (int32_t*)tmp;
     void* sc = nullptr;
-    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)2 * (size_t)D->max_slots * TM * NB));
+    // three regions: early slabs by level parity (two side streams), late slabs (main stream)
+    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)3 * (size_t)D->max_slots * TM * NB));
     D->allocs.push_back(sc);
     D->scratch = (double*)sc;
   }
@@ -807,7 +814,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
     if (!has_early(l)) return SCILMM_OK;
     hipStream_t sd = (l & 1) ? D->side2 : D->side;
-    if (l >= 2) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - 2)], 0));
+    // its youngest descendants sit look_depth + 1 levels below
+    if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)(l & 1) * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
@@ -825,17 +833,17 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
     return SCILMM_OK;
   };
-  {
-    int rc = S.nlevels > 1 ? launch_early(1) : SCILMM_OK;
+  for (int32_t l = 1; l <= D->look_depth && l < S.nlevels; ++l) {
+    int rc = launch_early(l);
     if (rc != SCILMM_OK) return rc;
   }
   for (int32_t l = 0; l < S.nlevels; ++l) {
     const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
     const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
-    double* sh = D->scratch + (size_t)(l & 1) * half;
-    // early(l+1) may start as soon as level l-1 is finished: issue it before this level's own kernels
-    if (l >= 1 && l + 1 < S.nlevels) {
-      int rc = launch_early(l + 1);
+    double* sh = D->scratch + (size_t)2 * half;
+    // early(l + depth) may start as soon as level l-1 is finished: issue it before this level's own kernels
+    if (l >= 1 && l + D->look_depth < S.nlevels) {
+      int rc = launch_early(l + D->look_depth);
       if (rc != SCILMM_OK) return rc;
     }
     if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
