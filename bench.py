@@ -28,6 +28,7 @@ WORKLOADS = {
     # name: (n individuals, sparsity_factor)  -- BASELINE.json configs[0..2]
     "10k": (10000, 0.001),
     "100k": (100000, 0.005),
+    "300k": (300000, 0.003),     # scaling probe between configs[1] and configs[2] (2.0e9 nnz(L), 7.6e13 flops)
     "1m": (1000000, 0.001),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; MI355X_MICROARCH.md lists no fp64 figure
@@ -95,10 +96,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)  # one rank per GPU under the driver; the modulo only matters in rehearsals
+    dev = torch.device("cuda", local_rank % ndev)
+    # "nccl" is RCCL.  SCILMM_BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks
+    backend = os.environ.get("SCILMM_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    rdev = dev if backend == "nccl" else torch.device("cpu")  # where the three reduced scalars live
 
     from scilmm_amd.factor import Symbolic
     t0 = time.time()
@@ -145,7 +153,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed, float(info.nnzL), logdets[-1]], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, float(info.nnzL), logdets[-1]], dtype=torch.float64, device=rdev)
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

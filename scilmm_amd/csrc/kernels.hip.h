@@ -772,17 +772,43 @@ __global__ __launch_bounds__(256) void k_update_compact(DevSym S, const UpdWork*
 // products  sum_k L_d[t,k] L_d[q,k]  of all its contributions in a fixed order.  No LDS, no barriers, no
 // atomics, bitwise reproducible.  Integer/latency-bound gather work, kept off the MFMA pipeline.
 __device__ __forceinline__ double cell_dot(const double* __restrict__ L, int64_t st, int64_t sq, int64_t md, int wd) {
+  // latency-bound gather: eight independent element pairs in flight per batch, fixed summation order
   const double* pt = L + st;
   const double* pq = L + sq;
-  double a0 = 0.0, a1 = 0.0;
+  double acc = 0.0;
   int k = 0;
-  for (; k + 2 <= wd; k += 2) {
-    a0 += pt[k * md] * pq[k * md];
-    a1 += pt[(k + 1) * md] * pq[(k + 1) * md];
+  for (; k + 8 <= wd; k += 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = pt[(int64_t)(k + u) * md];
+      b[u] = pq[(int64_t)(k + u) * md];
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0 += a[u] * b[u];
+      s1 += a[u + 1] * b[u + 1];
+    }
+    acc += s0 + s1;
   }
-  if (k < wd) a0 += pt[k * md] * pq[k * md];
-  return a0 + a1;
+  if (k < wd) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = min(k + u, wd - 1);  // clamped: the loads stay unconditional and independent
+      a[u] = pt[(int64_t)kk * md];
+      b[u] = pq[(int64_t)kk * md];
+    }
+    double s0 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s0 += (k + u < wd) ? a[u] * b[u] : 0.0;
+    acc += s0;
+  }
+  return acc;
 }
+
+struct CellSrc { int64_t st, sq; int32_t md, wd; };
 
 // groups [first, first+n_short) : one thread each;  groups [first+n_short, first+count) : one wave each
 __global__ __launch_bounds__(256) void k_sparse_cells(int64_t first, int64_t n_short, int64_t count,
@@ -797,8 +823,16 @@ __global__ __launch_bounds__(256) void k_sparse_cells(int64_t first, int64_t n_s
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= n_short) return;
     const int64_t g = first + u;
+    const int64_t c0 = grp_ptr[g], c1 = grp_ptr[g + 1];
     double acc = 0.0;
-    for (int64_t c = grp_ptr[g]; c < grp_ptr[g + 1]; ++c) acc += cell_dot(L, src_t[c], src_q[c], src_md[c], src_wd[c]);
+    // the descriptor of the next contribution is fetched while the current dot product runs
+    CellSrc cur{src_t[c0], src_q[c0], src_md[c0], src_wd[c0]};
+    for (int64_t c = c0; c < c1; ++c) {
+      const int64_t cn = min(c + 1, c1 - 1);
+      const CellSrc nxt{src_t[cn], src_q[cn], src_md[cn], src_wd[cn]};
+      acc += cell_dot(L, cur.st, cur.sq, cur.md, cur.wd);
+      cur = nxt;
+    }
     L[uniq_dst[g]] -= acc;
   } else {
     const int lane = threadIdx.x & 63;
