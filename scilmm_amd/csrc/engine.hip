@@ -732,7 +732,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     if (stc != SCILMM_OK) return stc;
   }
   const size_t sm_upd = sizeof(double) * (size_t)(2 * KC * LDA + 2 * KC * LDB) + sizeof(int32_t) * TM;
-  const size_t sm_potrf = sizeof(double) * (size_t)(NB * (NB + 1) + NB);
+  const size_t sm_potrf = sizeof(double) * (size_t)((NB / 2) * (NB + 1) + NJB * 16 * 17);
   hipStream_t st = D->stream;
   int64_t launches = 0;
   HIPCHK(hipEventRecord(D->ev[0], st));
@@ -1186,7 +1186,8 @@ int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor**
   HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * ((size_t)std::max<int64_t>(S.nnzL_stored, 1) + padL)));
   HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * ((size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1) + padI)));
   HIPCHK(hipMemset(f->L + (size_t)std::max<int64_t>(S.nnzL_stored, 1), 0, sizeof(double) * padL));
-  HIPCHK(hipMemset(f->invD + (size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1), 0, sizeof(double) * padI));
+  // (all of invD: k_potrf only ever writes the lower triangles, the upper ones must read as zero)
+  HIPCHK(hipMemset(f->invD, 0, sizeof(double) * ((size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1) + padI)));
   HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
   HIPCHK(hipMalloc((void**)&f->status, sizeof(int32_t)));
   return run_factorize(f, sigma2, bad_col);

@@ -916,25 +916,28 @@ __device__ unsigned long long g_potrf_prof[16];
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                double* __restrict__ invD, double* __restrict__ logd,
                                                int32_t* __restrict__ status) {
-  // One LDS array holds both triangles: T[i][k], i >= k is L; the inverse X (lower triangular) lives
-  // transposed in the strict upper part, X(r,c) = T[c][r] for r > c, with its diagonal in xd[].  34 KB, so a
-  // potrf workgroup fits on a CU next to two update workgroups (look-ahead keeps those resident).
-  constexpr int LD = NB + 1;
+  // LDS budget: the look-ahead keeps two 74 KB update workgroups resident on every CU, so a kernel of the main
+  // stream can only start where ONE of them has retired: <= 85 KB.  Only the lower triangle of L is kept, folded
+  // into NB/2 rows of NB+1 doubles (row i >= NB/2 holds L[i][0..i]; the rest of that row holds row NB-1-i), plus
+  // the eight 16 x 16 diagonal inverses: 83.5 KB.  The off-diagonal blocks of the inverse never touch LDS (phase 2).
+  constexpr int LDF = NB + 1, HB = NB / 2, XS = 16 * 17;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* T = smem;             // [NB][LD]
-  double* xd = smem + NB * LD;  // [NB]
+  double* F = smem;                 // [HB][LDF] folded lower triangle
+  double* Xd = smem + HB * LDF;     // [NJB][16][17]  Xd[kb][n][k] = X(16 kb + n, 16 kb + k), zero above the diagonal
+#define FA(i, k) (((i) >= HB) ? ((i) - HB) * LDF + (k) : (HB - 1 - (i)) * LDF + (NB - (i)) + (k))
+  __builtin_amdgcn_s_setprio(3);  // latency chain of the main stream: issue ahead of the co-resident update waves
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t s = fronts[blockIdx.x];
   const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   double* P = L + S.sn_loff[s];
+  double* I = invD + S.inv_off[s];
   const int nb = (w + 15) >> 4, W = nb << 4;  // padded with an identity block
 #ifdef SCILMM_POTRF_PROF
   unsigned long long tprev_ = wall_clock64();
   if (w == NB && tid == 0) atomicAdd(&g_potrf_prof[15], 1ull);
 #endif
-#define XINV(r, c) ((r) > (c) ? T[(c) * LD + (r)] : ((r) == (c) ? xd[(r)] : 0.0))
-  // lower triangle of the block -> LDS, eight loads in flight per thread (the strict upper part starts as zero)
+  // lower triangle of the block -> LDS, eight loads in flight per thread
   for (int base = tid; base < W * W; base += 256 * 8) {
     double v[8];
 #pragma unroll
@@ -942,27 +945,28 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       const int idx = base + 256 * u;
       const int k = idx / W, i = idx - k * W;
       v[u] = (i == k) ? 1.0 : 0.0;
-      if (idx < W * W && i < w && k < w) v[u] = (i >= k) ? P[(int64_t)k * m + i] : 0.0;
+      if (idx < W * W && i < w && k < w && i >= k) v[u] = P[(int64_t)k * m + i];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int idx = base + 256 * u;
       const int k = idx / W, i = idx - k * W;
-      if (idx < W * W) T[i * LD + k] = v[u];
+      if (idx < W * W && i >= k) F[FA(i, k)] = v[u];
     }
   }
-  if (tid < NB) xd[tid] = 1.0;
   __syncthreads();
   PPROF(0);
+  const int li = lane & 15, lk = lane >> 4;
   for (int kb = 0; kb < nb; ++kb) {
     const int o = kb << 4;
+    double* Xk = Xd + kb * XS;
     if (wv == 0) {
       // ---- 16 x 16 diagonal block in registers, right-looking: lane r (mod 16) owns row r of L; the pivot
       //      column is broadcast with v_readlane (scalar operands), so a step is one rsqrt + independent FMAs
       const int r = lane & 15;
       double a[16], x[16], rs[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? T[(o + r) * LD + o + c] : 0.0;
+      for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? F[FA(o + r, o + c)] : 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double dj = bc_lane(a[j], j);
@@ -990,10 +994,10 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
       if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          if (c <= r) T[(o + r) * LD + o + c] = a[c];        // L(o+r, o+c)
-          if (c > r) T[(o + r) * LD + o + c] = x[c];         // X(o+c, o+r), c > r, stored transposed
+          if (c <= r) F[FA(o + r, o + c)] = a[c];  // L(o+r, o+c)
+          Xk[c * 17 + r] = x[c];                   // X(o+c, o+r); zero for c < r
+          if (c >= r && o + c < w && o + r < w) I[(int64_t)(o + r) * w + o + c] = x[c];
         }
-        xd[o + r] = x[r];
       }
     }
     __syncthreads();
@@ -1001,21 +1005,15 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     const int nrem = W - o - 16;
     if (nrem > 0) {
       const int nbr = nrem >> 4;
-      const int li = lane & 15, lk = lane >> 4;
       // ---- panel below: B_ib = A_ib * Dinv^T, one wave per 16-row block, MFMA, in place
-      //      D[m][n] = sum_k A[m][k] Dinv[n][k];  Dinv[n][k] = X(o+n, o+k), lower triangular, diagonal in xd
+      //      D[m][n] = sum_k A[m][k] Dinv[n][k];  Dinv[n][k] = X(o+n, o+k) = Xk[n][k]
       for (int ib = wv; ib < nbr; ib += 4) {
         const int r0 = o + 16 + 16 * ib;
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k4 = 0; k4 < 16; k4 += 4) {
-          const int k = k4 + lk;
-          const double av = T[(r0 + li) * LD + o + k];
-          const double bv = (k < li) ? T[(o + k) * LD + o + li] : ((k == li) ? xd[o + li] : 0.0);
-          acc = mfma_f64(av, bv, acc);
-        }
+        for (int k4 = 0; k4 < 16; k4 += 4) acc = mfma_f64(F[FA(r0 + li, o + k4 + lk)], Xk[li * 17 + k4 + lk], acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(r0 + lk + 4 * r) * LD + o + li] = acc[r];
+        for (int r = 0; r < 4; ++r) F[FA(r0 + lk + 4 * r, o + li)] = acc[r];
       }
       __syncthreads();
       PPROF(2);
@@ -1027,79 +1025,70 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
           const int r0 = o + 16 + 16 * ib, q0 = o + 16 + 16 * kk;
           d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int k4 = 0; k4 < 16; k4 += 4) {
-            const double av = T[(r0 + li) * LD + o + k4 + lk];
-            const double bv = T[(q0 + li) * LD + o + k4 + lk];
-            acc = mfma_f64(av, bv, acc);
-          }
+          for (int k4 = 0; k4 < 16; k4 += 4) acc = mfma_f64(F[FA(r0 + li, o + k4 + lk)], F[FA(q0 + li, o + k4 + lk)], acc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = r0 + lk + 4 * r, col = q0 + li;
-            if (row >= col) T[row * LD + col] -= acc[r];  // the strict upper part belongs to the inverse
+            if (row >= col) F[FA(row, col)] -= acc[r];
           }
         }
       __syncthreads();
       PPROF(3);
     }
   }
-  // ---- inverse of the whole block by block sub-diagonals: X_ij = -X_ii * sum_{kb=j}^{i-1} L_{i,kb} X_{kb,j}
-  //      one wave per 16 x 16 block (i = j + d): both products are MFMA chains; the intermediate goes through
-  //      the block's own LDS cells (same wave, in-order LDS => no workgroup barrier inside a sub-diagonal)
-  for (int d = 1; d < nb; ++d) {
-    const int nblk = nb - d;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int blk = wv; blk < nblk; blk += 4) {
-      const int i0 = (blk + d) << 4, j0 = blk << 4;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int kb0 = j0; kb0 < i0; kb0 += 16) {
+  // ---- inverse, off-diagonal blocks, one block COLUMN per wave (columns j and nb-1-j for balance):
+  //      X_ij = -X_ii * sum_{kb=j}^{i-1} L_{i,kb} X_{kb,j}.  An MFMA result block D[(l>>4)+4r][l&15] is, lane by
+  //      lane, exactly the B operand of the next product (k-step s takes acc[s]), so the finished blocks of a
+  //      column stay in registers: no LDS traffic, no barriers; they go straight to invD.
+  for (int j = 0; j < nb; ++j) {
+    const int owner = (j < (nb + 1) / 2) ? (j & 3) : ((nb - 1 - j) & 3);  // long columns paired with short ones
+    if (owner != wv) continue;
+    d4 xb[NJB];
 #pragma unroll
-        for (int k4 = 0; k4 < 16; k4 += 4) {
-          const int k = kb0 + k4 + lk;               // global column of L / row of X
-          const double av = T[(i0 + li) * LD + k];   // L(i0+li, k)
-          const int col = j0 + li;                   // X(k, col)
-          const double bv = (k > col) ? T[col * LD + k] : ((k == col) ? xd[col] : 0.0);
-          acc = mfma_f64(av, bv, acc);
+    for (int r = 0; r < 4; ++r) xb[0][r] = Xd[j * XS + (lk + 4 * r) * 17 + li];  // X_jj in result layout
+#pragma unroll
+    for (int di = 1; di < NJB; ++di) {
+      const int i = j + di;
+      if (i < nb) {
+        d4 sacc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int dk = 0; dk < NJB; ++dk)
+          if (dk < di) {
+            const int kb = j + dk;
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep)
+              sacc = mfma_f64(F[FA(16 * i + li, 16 * kb + 4 * sstep + lk)], xb[dk][sstep], sacc);
+          }
+        d4 yacc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sstep = 0; sstep < 4; ++sstep) yacc = mfma_f64(Xd[i * XS + li * 17 + 4 * sstep + lk], sacc[sstep], yacc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          xb[di][r] = -yacc[r];
+          const int row = 16 * i + lk + 4 * r, col = 16 * j + li;
+          if (row < w && col < w) I[(int64_t)col * w + row] = -yacc[r];
         }
       }
-      // temp(i0 + row, j0 + col) parked at X's own cells: X(r, c) = T[c][r]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) T[(j0 + li) * LD + i0 + lk + 4 * r] = acc[r];
-      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      d4 acc2 = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k4 = 0; k4 < 16; k4 += 4) {
-        const int k = k4 + lk;
-        // X_ii(m = li, k): lower triangular
-        const double av = (k < li) ? T[(i0 + k) * LD + i0 + li] : ((k == li) ? xd[i0 + li] : 0.0);
-        const double bv = T[(j0 + li) * LD + i0 + k];  // temp(i0 + k, j0 + li)
-        acc2 = mfma_f64(av, bv, acc2);
-      }
-      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 4; ++r) T[(j0 + li) * LD + i0 + lk + 4 * r] = -acc2[r];
     }
-    __syncthreads();
   }
   PPROF(4);
   {
     // sum(log diag): one log per thread, wave reduction, fixed summation order
     __shared__ double lgp[4];
     double lg = 0.0;
-    for (int j = tid; j < w; j += 256) lg += log(T[j * LD + j]);
+    for (int jj = tid; jj < w; jj += 256) lg += log(F[FA(jj, jj)]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off, 64);
     if (lane == 0) lgp[wv] = lg;
     __syncthreads();
     if (tid == 0) logd[s] = (lgp[0] + lgp[1]) + (lgp[2] + lgp[3]);
   }
-  double* I = invD + S.inv_off[s];
   for (int idx = tid; idx < w * w; idx += 256) {
     const int k = idx / w, i = idx - k * w;
-    P[(int64_t)k * m + i] = (i >= k) ? T[i * LD + k] : 0.0;
-    I[k * w + i] = XINV(i, k);
+    P[(int64_t)k * m + i] = (i >= k) ? F[FA(i, k)] : 0.0;
   }
   PPROF(5);
-#undef XINV
+#undef FA
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1110,6 +1099,7 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
                                               const double* __restrict__ invD) {
   __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
   __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int32_t g = tiles[blockIdx.x];
   const int32_t s = S.tile_front[g];
