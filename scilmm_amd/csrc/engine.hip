@@ -77,11 +77,20 @@ struct Dev {
     int32_t* wd = nullptr;
     std::vector<int64_t> level_ptr;    // [nlevels+1] over unique target cells
     std::vector<int64_t> level_short;  // [nlevels] short groups (listed first) per level
-  } cellset[2];
+  } cellset[3];  // 0 = early (side streams), 1 = late (main stream; split levels: diagonal tile only), 2 = late, rest stream
   int64_t n_dense_combos = 0, n_sparse_combos = 0, n_cells = 0;
   std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
   int ablate = 0;
+  // chain levels in split mode: only [late update of the diagonal tile, potrf, trsm of the rows the next diagonal
+  // block needs] stay on the main stream; the other tiles' late update and trsm run one step behind on `rest`
+  hipStream_t rest = nullptr;
+  std::vector<uint8_t> split_lv;        // [nlevels]
+  std::vector<int64_t> work_split;      // [nlevels] late items of the diagonal tile (they come first in the level)
+  std::vector<int64_t> red_split;       // [nlevels] late reduce tiles of the diagonal tile
+  int32_t* d_trsm_split = nullptr;      // per split level: critical tiles, then the rest
+  std::vector<int64_t> trsm_sptr;       // [2 nlevels + 1]
+  std::vector<hipEvent_t> chain_ev;     // 3 per level: potrf done, rest-stream late update done, critical trsm done
   int look_depth = 2;      // "late" = descendants at most this many levels below the target; older ones are "early"
   int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
@@ -142,6 +151,9 @@ void dev_free(void* p) {
   if (D->ev_asm) (void)hipEventDestroy(D->ev_asm);
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->side2) (void)hipStreamDestroy(D->side2);
+  if (D->rest) (void)hipStreamDestroy(D->rest);
+  for (auto& e : D->chain_ev)
+    if (e) (void)hipEventDestroy(e);
   if (D->stream) (void)hipStreamDestroy(D->stream);
   delete D;
 }
@@ -191,6 +203,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
     }
   }
+  {
+    int lo2 = 0, hi2 = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo2, &hi2));
+    HIPCHK(hipStreamCreateWithPriority(&D->rest, hipStreamNonBlocking, hi2));
+  }
+  D->chain_ev.assign((size_t)3 * std::max(sym->S->nlevels, 1), nullptr);
+  for (auto& e : D->chain_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&D->ev_asm, hipEventDisableTiming));
   D->lev_ev.assign((size_t)2 * std::max(S.nlevels, 1), nullptr);
   for (auto& e : D->lev_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -256,6 +275,30 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->look_depth = eld ? std::max(1, atoi(eld)) : 2;  // measured at 100k: depth 1 81.4 ms, 2 77.6 ms, 3 78.4 ms
     }
     const int32_t depth = D->look_depth;
+    D->split_lv.assign(std::max(S.nlevels, 1), 0);
+    std::vector<int32_t> crit_t0(std::max(S.nlevels, 1), 0), crit_t1(std::max(S.nlevels, 1), -1);
+    {
+      // Opt-in (SCILMM_SPLIT_CHAIN=1): measured at the 100k pedigree it moves factorize from 74.7 to 73.8 ms only --
+      // the rest stream's [trsm of level l-1, late update of level l] is as long as the main stream's chain, and
+      // under the saturating early updates both run ~1.6x slower than isolated.
+      const char* ens = getenv("SCILMM_SPLIT_CHAIN");
+      const char* ecp = getenv("SCILMM_COMPACT");
+      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1');
+      int64_t why[3] = {0, 0, 0};
+      for (int32_t l = 1; allow && l + 1 < S.nlevels; ++l) {
+        if (S.level_ptr[l + 1] - S.level_ptr[l] != 1 || S.level_ptr[l + 2] - S.level_ptr[l + 1] != 1) continue;
+        const int32_t sf = S.level_fronts[S.level_ptr[l]], sn = S.level_fronts[S.level_ptr[l + 1]];
+        if (S.sn_start[sf + 1] - S.sn_start[sf] != TM) { why[0]++; continue; }  // tile 0 must be exactly the diagonal block
+        why[2]++;
+        for (int64_t e = S.upd_ptr[sn]; e < S.upd_ptr[sn + 1]; ++e)
+          if (S.upd_src[e] == sf) {
+            crit_t0[l] = S.upd_p0[e] / TM;
+            crit_t1[l] = (S.upd_p1[e] - 1) / TM;
+            D->split_lv[l] = 1;
+          }
+      }
+      if (getenv("SCILMM_VERBOSE")) fprintf(stderr, "[scilmm plan] split candidates: width!=TM %lld, tiles unordered %lld, passed %lld\n", (long long)why[0], (long long)why[1], (long long)why[2]);
+    }
     std::vector<ComboDesc> late_tmp;
     // compact combos, same early | late grouping per tile
     // (each compact combo is cut at tile row TM/2: work item = (tile, half), which owns its cells exclusively)
@@ -268,7 +311,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const bool allow_compact = enoc && enoc[0] == '1';
     const char* ecf = getenv("SCILMM_COMPACT_FACTOR");
     const double compact_factor = ecf ? atof(ecf) : 2.0;
-    struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };
+    struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };  // late: 0 early, 1 late (main), 2 late (rest stream)
     std::vector<Cell> cells;
     cd.reserve((size_t)nc / 2 + 16);
     for (int64_t g = 0; g < ntiles0; ++g) {
@@ -343,8 +386,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           for (int32_t q = x.p0; q < x.p0 + x.nq; ++q) {
             const int64_t j = rd[q] - c0s;
             if (R < j) continue;  // strict upper part of the diagonal block is never referenced
+            const bool clate = !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr];
             cells.push_back(Cell{S.sn_loff[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr],
-                                 (!lookahead || S.sn_level[d] + depth >= S.sn_level[sfr]) ? 1 : 0});
+                                 clate ? ((D->split_lv[S.sn_level[sfr]] && ti > 0) ? 2 : 1) : 0});
           }
         }
       }
@@ -369,11 +413,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       return a.sq < b.sq;
     });
     {
-      size_t split = 0;
+      size_t split = 0, split2 = 0;
       while (split < cells.size() && cells[split].late == 0) ++split;
+      split2 = split;
+      while (split2 < cells.size() && cells[split2].late == 1) ++split2;
       int64_t ngroups_total = 0;
-      for (int which = 0; which < 2; ++which) {
-        const size_t cb0 = which == 0 ? 0 : split, ce0 = which == 0 ? split : cells.size();
+      for (int which = 0; which < 3; ++which) {
+        const size_t cb0 = which == 0 ? 0 : (which == 1 ? split : split2);
+        const size_t ce0 = which == 0 ? split : (which == 1 ? split2 : cells.size());
         // groups of cells sharing one target address; inside a level the short groups come first
         struct Grp { int64_t dst, b, e; int32_t level; };
         std::vector<Grp> groups;
@@ -428,6 +475,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<int32_t> pslot_e(pslot.size(), 0), pnseg_e(pslot.size(), 0), red_tiles_e;
     D->red_ptr_e.assign(S.nlevels + 1, 0);
     std::vector<UpdWork> work, work_early, cwork, cwork_early;
+    D->work_split.assign(std::max(S.nlevels, 1), 0);
+    D->red_split.assign(std::max(S.nlevels, 1), 0);
     D->cwork_ptr.assign(S.nlevels + 1, 0);
     D->cearly_ptr.assign(S.nlevels + 1, 0);
     D->work_ptr.assign(S.nlevels + 1, 0);
@@ -442,7 +491,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // fills the chip once with balanced items (late levels of a dense chain: few tiles, long combo lists).
     auto combo_cost_d = [&](int64_t c) -> int64_t { return 1 + (cd[c].wd + KC - 1) / KC; };
     auto combo_cost = [&](int64_t c) -> int64_t { return combo_cost_d(c); };
-    const int64_t target_items = 1024, min_item = 24;
+    // ... but an item never exceeds max_item units (~0.5 ms): the main stream's kernels start in the slots that
+    // retiring update items free, so long items starve the per-level chain (300k probe: 2.3 ms per trsm launch)
+    const char* emi = getenv("SCILMM_MAX_ITEM");
+    const int64_t target_items = 1024, min_item = 24, max_item = emi ? atoll(emi) : 96;
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
       if (ce <= cb) return 0;
@@ -471,11 +523,19 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost_d(c);
       }
       const int64_t big = (int64_t)1 << 60;
-      const int64_t per_e = allow_split ? std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items) : big;
-      const int64_t per_l = allow_split ? std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items) : big;
+      const int64_t per_e = allow_split ? std::min(max_item, std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items)) : big;
+      const int64_t per_l = allow_split ? std::min(max_item, std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items)) : big;
       int64_t slots = 0;
-      for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
-        const int32_t g = S.level_tiles[i];
+      // a split level lists its diagonal tile first: the late items / reduce entries of that tile lead the level
+      std::vector<int32_t> order(S.level_tiles.begin() + S.level_tile_ptr[l], S.level_tiles.begin() + S.level_tile_ptr[l + 1]);
+      if (D->split_lv[l]) {
+        const int32_t g0 = (int32_t)S.tile_base[S.level_fronts[S.level_ptr[l]]];
+        auto it = std::find(order.begin(), order.end(), g0);
+        if (it != order.end()) std::rotate(order.begin(), it, it + 1);
+        else D->split_lv[l] = 0;
+      }
+      for (size_t oi = 0; oi < order.size(); ++oi) {
+        const int32_t g = order[oi];
         const size_t fe = work_early.size(), fl = work.size();
         const int64_t ne = cut(g, dptr[g], dmid[g], per_e, work_early);
         const int64_t nl = cut(g, dmid[g], dptr[g + 1], per_l, work);
@@ -504,6 +564,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + k);
           slots += pl;
         }
+        if (oi == 0) {  // first tile of the level = the diagonal tile of a split level's front
+          D->work_split[l] = (int64_t)work.size() - D->work_ptr[l];
+          D->red_split[l] = (int64_t)red_tiles.size() - D->red_ptr[l];
+        }
       }
       max_slots = std::max(max_slots, slots);
       D->lev_cost_e.push_back(total_e);
@@ -516,6 +580,36 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->red_ptr_e[l + 1] = (int64_t)red_tiles_e.size();
     }
     D->max_slots = std::max<int64_t>(max_slots, 1);
+    {
+      std::vector<int32_t> tl;
+      D->trsm_sptr.assign((size_t)2 * S.nlevels + 1, 0);
+      for (int32_t l = 0; l < S.nlevels; ++l) {
+        if (D->split_lv[l]) {
+          const int64_t lt0 = S.level_tile_ptr[l], lt1 = S.level_tile_ptr[l + 1];
+          const int64_t gb = S.tile_base[S.level_fronts[S.level_ptr[l]]];
+          for (int64_t i = lt0; i < lt1; ++i) {
+            const int64_t rel = S.level_tiles[i] - gb;
+            if (rel >= crit_t0[l] && rel <= crit_t1[l]) tl.push_back(S.level_tiles[i]);
+          }
+          D->trsm_sptr[2 * l + 1] = (int64_t)tl.size();
+          for (int64_t i = lt0; i < lt1; ++i) {
+            const int64_t rel = S.level_tiles[i] - gb;
+            if (!(rel >= crit_t0[l] && rel <= crit_t1[l])) tl.push_back(S.level_tiles[i]);
+          }
+        } else {
+          D->trsm_sptr[2 * l + 1] = (int64_t)tl.size();
+        }
+        D->trsm_sptr[2 * l + 2] = (int64_t)tl.size();
+      }
+      if (tl.empty()) tl.push_back(0);
+      if ((st = upload(sym, D, tl, &tmp)) != SCILMM_OK) return st;
+      D->d_trsm_split = (int32_t*)tmp;
+      if (getenv("SCILMM_VERBOSE")) {
+        int64_t nsp = 0;
+        for (int32_t l = 0; l < S.nlevels; ++l) nsp += D->split_lv[l];
+        fprintf(stderr, "[scilmm plan] split chain levels: %lld of %d\n", (long long)nsp, S.nlevels);
+      }
+    }
     {
       if (ccd.empty()) ccd.push_back(ComboDesc{});
       const ComboDesc* dcc;
@@ -763,6 +857,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   HIPCHK(hipEventRecord(D->ev_asm, st));
   HIPCHK(hipStreamWaitEvent(D->side, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->side2, D->ev_asm, 0));
+  HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
   const bool prof = D->profiling;
   constexpr int PE = 8;  // profiling events per level
   if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
@@ -846,37 +941,83 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
       int rc = launch_early(l + D->look_depth);
       if (rc != SCILMM_OK) return rc;
     }
-    if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
-    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
     const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
-    if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
-    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
     const int64_t r0 = D->red_ptr[l], r1 = D->red_ptr[l + 1];
-    if (r1 > r0) {
-      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (r1 - r0))), dim3(128), 0, st, D->v, D->d_red_tiles + r0, D->d_tile_pslot,
+    auto launch_reduce = [&](hipStream_t stream, int64_t q0, int64_t q1) {
+      if (q1 <= q0) return;
+      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (q1 - q0))), dim3(128), 0, stream, D->v, D->d_red_tiles + q0, D->d_tile_pslot,
                          D->d_tile_pnseg, (const double*)sh, fac->L);
       launches++;
-    }
-    launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
-    launch_cells(st, 1, l);
-    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
-    if (f1 > f0) {
-      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
-                         fac->invD, fac->logd, fac->status);
-      launches++;
-    }
-    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
-    if (t1 > t0) {
+    };
+    auto launch_trsm = [&](hipStream_t stream, const int32_t* tiles, int64_t cnt) {
+      if (cnt <= 0) return;
       if (D->use_mfma)
-        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
-                           fac->invD);
+        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
       else
-        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L,
-                           fac->invD);
+        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
       launches++;
+    };
+    // a level that follows a split level: its predecessor's tail (the other tiles' trsm) ended on the rest stream
+    const bool prev_split = l >= 1 && D->split_lv[l - 1];
+    if (!D->split_lv[l]) {
+      if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
+      if (prev_split) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - 1)], 0));
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
+      if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
+      launch_reduce(st, r0, r1);
+      launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
+      launch_cells(st, 1, l);
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
+      if (f1 > f0) {
+        hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
+                           fac->invD, fac->logd, fac->status);
+        launches++;
+      }
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
+      launch_trsm(st, D->d_level_tiles + t0, t1 - t0);
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
+      HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
+    } else {
+      // ---- split chain level.  Main stream: late update of the diagonal tile, potrf, then trsm of the tiles the
+      //      NEXT diagonal block is updated from.  Rest stream: late update of the other tiles, then their trsm.
+      hipStream_t rs = D->rest;
+      hipEvent_t e_potrf = D->chain_ev[3 * l + 0], e_lur = D->chain_ev[3 * l + 1], e_t1 = D->chain_ev[3 * l + 2];
+      const int64_t ws = D->work_split[l], rsplit = D->red_split[l];
+      // main: needs early(l); level l-2 complete (its panels are read by the late items: depth 2); the critical
+      // rows of level l-1 (same stream if l-1 was split, else the whole level l-1 ran on this stream)
+      if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
+      for (int32_t back = 2; back <= D->look_depth && back <= l; ++back)
+        if (D->split_lv[l - back]) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - back)], 0));
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
+      if (ws > 0) launch_update(st, D->d_work + w0, ws, sh);
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
+      launch_reduce(st, r0, r0 + rsplit);
+      launch_cells(st, 1, l);
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
+      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L, fac->invD,
+                         fac->logd, fac->status);
+      launches++;
+      HIPCHK(hipEventRecord(e_potrf, st));
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
+      // rest: the other tiles of panel l.  Needs early(l) and ALL of level l-1 (and older late levels).
+      if (has_early(l)) HIPCHK(hipStreamWaitEvent(rs, D->lev_ev[2 * l + 1], 0));
+      for (int32_t back = 1; back <= D->look_depth && back <= l; ++back) HIPCHK(hipStreamWaitEvent(rs, D->lev_ev[2 * (l - back)], 0));
+      if (w1 > w0 + ws) launch_update(rs, D->d_work + w0 + ws, w1 - w0 - ws, sh);
+      launch_reduce(rs, r0 + rsplit, r1);
+      launch_cells(rs, 2, l);
+      HIPCHK(hipEventRecord(e_lur, rs));
+      // main: critical trsm tiles (their late update ran on the rest stream)
+      HIPCHK(hipStreamWaitEvent(st, e_lur, 0));
+      launch_trsm(st, D->d_trsm_split + D->trsm_sptr[2 * l], D->trsm_sptr[2 * l + 1] - D->trsm_sptr[2 * l]);
+      HIPCHK(hipEventRecord(e_t1, st));
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
+      // rest: the remaining trsm tiles; the level is complete when both parts are
+      HIPCHK(hipStreamWaitEvent(rs, e_potrf, 0));
+      launch_trsm(rs, D->d_trsm_split + D->trsm_sptr[2 * l + 1], D->trsm_sptr[2 * l + 2] - D->trsm_sptr[2 * l + 1]);
+      HIPCHK(hipStreamWaitEvent(rs, e_t1, 0));
+      HIPCHK(hipEventRecord(D->lev_ev[2 * l], rs));
     }
-    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
-    HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
   }
   HIPCHK(hipEventRecord(D->ev[2], st));
   HIPCHK(hipGetLastError());
@@ -885,6 +1026,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(D->side));
   HIPCHK(hipStreamSynchronize(D->side2));
+  HIPCHK(hipStreamSynchronize(D->rest));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));

@@ -196,6 +196,20 @@ def test_compact_update_path_matches_oracle(monkeypatch):
     assert np.abs(V @ f(b) - b).max() < 1e-9
 
 
+def test_split_chain_schedule_is_bitwise_identical(monkeypatch):
+    """Opt-in split schedule of the chain levels (SCILMM_SPLIT_CHAIN=1): same kernels per cell, so the same bits."""
+    from scilmm_amd.harness.pedigree import make_problem
+    mats, C, y = make_problem(30000, 0.005, seed=3)
+    A = mats[0]
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    f0 = _engine([A, I]).factorize([0.4, 0.6])
+    monkeypatch.setenv("SCILMM_SPLIT_CHAIN", "1")
+    f1 = _engine([A, I]).factorize([0.4, 0.6])
+    assert f0.logdet() == f1.logdet()
+    assert np.array_equal(f0.L().data, f1.L().data)
+
+
 def test_full_size_properties_100k():
     """BASELINE config 2 (100k, sf 0.005) at full size through size-independent properties."""
     from scilmm_amd.harness.pedigree import make_problem
