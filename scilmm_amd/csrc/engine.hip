@@ -265,7 +265,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const int64_t nc = (int64_t)S.combo_pair.size();
     const int64_t ntiles0 = (int64_t)S.tile_front.size();
     const char* ecs = getenv("SCILMM_CELL_LIMIT");
-    const double cell_limit = ecs ? atof(ecs) : 1024.0;  // pairs with cells*width below this take the cell-wise path
+    const double cell_limit = ecs ? atof(ecs) : 2048.0;  // pairs with cells*width below this take the cell-wise path
     std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
     std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
     const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
@@ -494,7 +494,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // ... but an item never exceeds max_item units (~0.5 ms): the main stream's kernels start in the slots that
     // retiring update items free, so long items starve the per-level chain (300k probe: 2.3 ms per trsm launch)
     const char* emi = getenv("SCILMM_MAX_ITEM");
-    const int64_t target_items = 1024, min_item = 24, max_item = emi ? atoll(emi) : 96;
+    const char* eti = getenv("SCILMM_TARGET_ITEMS");
+    const char* emn = getenv("SCILMM_MIN_ITEM");
+    const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
       if (ce <= cb) return 0;
