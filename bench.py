@@ -142,7 +142,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    prof = {"update_ms": 0.0, "potrf_ms": 0.0, "trsm_ms": 0.0, "reduce_cells_ms": 0.0, "assemble_ms": 0.0, "factor_ms": 0.0,
+    prof = {"update_union_ms": 0.0, "update_ms": 0.0, "potrf_ms": 0.0, "trsm_ms": 0.0, "reduce_cells_ms": 0.0, "assemble_ms": 0.0, "factor_ms": 0.0,
             "solve_fwd_ms": 0.0, "solve_bwd_ms": 0.0, "n_update_launches": 0, "n_launches": 0}
     for i in range(args.steps):
         step(i)
@@ -202,10 +202,13 @@ def main():
                        "update_ms": prof["update_ms"] / K, "potrf_ms": prof["potrf_ms"] / K,
                        "trsm_ms": prof["trsm_ms"] / K, "reduce_cells_ms": prof["reduce_cells_ms"] / K, "launches_per_factorize": prof["n_launches"] / K,
                        "symbolic_s": t_sym, "generate_s": t_gen, "logdet": logdet_total, "logdet_at_0.4_0.6": logdet_ref_point, "solve_residual": resid},
-            "roofline": {"bound": "mfma", "kernel": "k_update<true> (fp64 MFMA supernodal update)",
+            "roofline": {"bound": "mfma", "kernel": "k_update2<true> (fp64 MFMA supernodal update)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "measured_sustained_mfma_f64_tflops": 49.4,
+                         # launches of consecutive levels overlap on two streams: the same flops over the time during
+                         # which at least one update launch was running (not the figure the contract asks for)
+                         "achieved_over_busy_time": info.update_flops * K / max(prof["update_union_ms"] / 1e3, 1e-12) / 1e12,
                          "flops_per_launch": info.update_flops / n_upd * K,
                          "avg_launch_ms": prof["update_ms"] / n_upd,
                          "launches": int(n_upd)},

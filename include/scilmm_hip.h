@@ -80,6 +80,11 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k);
  * *bad_col receives the failing (permuted) column. */
 int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor** out, int32_t* bad_col);
 int scilmm_refactorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col);
+/* Queue the same work and return at once: the host can draw the next normal matrix (np.random.randn(n,100),
+ * SparseCholesky.py:50) while the device factorizes.  scilmm_factor_wait -- or any call that uses the factor --
+ * completes it and reports SCILMM_ERR_NOT_PD / *bad_col exactly like scilmm_refactorize. */
+int scilmm_refactorize_async(scilmm_factor* fac, const double* sigma2);
+int scilmm_factor_wait(scilmm_factor* fac, int32_t* bad_col);
 void scilmm_factor_free(scilmm_factor* fac);
 
 /* factor.logdet()  (SparseCholesky.py:40) */
@@ -110,6 +115,9 @@ typedef struct scilmm_timing {
   double update_ms, potrf_ms, trsm_ms;
   int64_t n_update_launches;
   double reduce_cells_ms;
+  /* wall time during which at least one update launch was running (early launches of consecutive levels
+   * overlap on the two side streams, so update_ms -- the SUM of launch durations -- counts that time twice) */
+  double update_union_ms;
 } scilmm_timing;
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
 /* Bracket every kernel class of the factorization with HIP events on the handle's stream (bench.py's

@@ -165,14 +165,18 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
     sym = cholesky_func.engine_for(mats)
     state = cholesky_func.__dict__.setdefault('_factor_state', {})
     fac = state.get(id(sym))
+    n = y.size
+    c = covariates.shape[1]
     if fac is None:
         state.clear()
         fac = state[id(sym)] = sym.factorize(sig2g_array)
+        R = np.random.randn(n, sim_num)
     else:
-        fac.refactorize(sig2g_array)
-    n = y.size
-    c = covariates.shape[1]
-    R = np.random.randn(n, sim_num)
+        # the device factorizes while the host draws the normal matrix (same np.random stream as the reference:
+        # one randn(n, sim_num) per evaluation, SparseCholesky.py:50); wait() raises NotPositiveDefiniteError
+        fac.refactorize_async(sig2g_array)
+        R = np.random.randn(n, sim_num)
+        fac.wait()
     Z = fac.lmul(R)
     if cholesky_func.fused:
         X = fac(np.hstack([covariates, y[:, None], Z]))

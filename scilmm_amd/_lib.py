@@ -50,14 +50,15 @@ class Timing(C.Structure):
     _fields_ = [("assemble_ms", C.c_double), ("factor_ms", C.c_double), ("solve_fwd_ms", C.c_double),
                 ("solve_bwd_ms", C.c_double), ("lmul_ms", C.c_double), ("quad_ms", C.c_double),
                 ("n_launches", C.c_int64), ("update_ms", C.c_double), ("potrf_ms", C.c_double),
-                ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64), ("reduce_cells_ms", C.c_double)]
+                ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64), ("reduce_cells_ms", C.c_double),
+                ("update_union_ms", C.c_double)]
 
 
 # every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "scilmm_symbolic_create", "scilmm_symbolic_info", "scilmm_symbolic_get", "scilmm_symbolic_error",
     "scilmm_symbolic_free", "scilmm_values_upload", "scilmm_factorize", "scilmm_refactorize",
-    "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
+    "scilmm_refactorize_async", "scilmm_factor_wait", "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
     "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
@@ -87,6 +88,8 @@ def lib():
     L.scilmm_values_upload.argtypes = [vp, i32, vp]
     L.scilmm_factorize.argtypes = [vp, vp, P(vp), P(i32)]
     L.scilmm_refactorize.argtypes = [vp, vp, P(i32)]
+    L.scilmm_refactorize_async.argtypes = [vp, vp]
+    L.scilmm_factor_wait.argtypes = [vp, P(i32)]
     L.scilmm_factor_free.argtypes = [vp]
     L.scilmm_factor_free.restype = None
     L.scilmm_logdet.argtypes = [vp, P(dbl)]

@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -171,6 +174,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   Dev* D = new Dev();
   sym->device = D;
   sym->device_free = dev_free;
+  const bool pverb = getenv("SCILMM_VERBOSE") != nullptr;
+  auto ptl = std::chrono::steady_clock::now();
+  auto plap = [&](const char* what) {
+    auto now = std::chrono::steady_clock::now();
+    if (pverb) fprintf(stderr, "[scilmm plan] %-30s %8.3f s\n", what, std::chrono::duration<double>(now - ptl).count());
+    ptl = now;
+  };
   for (auto& e : D->ev) e = nullptr;
   const Symbolic& S = *sym->S;
   {
@@ -260,6 +270,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   D->vals.assign(S.K, nullptr);
   D->have_vals.assign(S.K, 0);
   HIPCHK(hipMalloc((void**)&D->d_out, sizeof(double) * RPMAX));
+  plap("symbolic arrays -> device");
   // ---- update-kernel plan
   {
     const int64_t nc = (int64_t)S.combo_pair.size();
@@ -405,13 +416,39 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->n_dense_combos = (int64_t)cd.size();
 
     D->n_cells = (int64_t)cells.size();
-    std::sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) {
-      if (a.late != b.late) return a.late < b.late;
-      if (a.level != b.level) return a.level < b.level;
-      if (a.dst != b.dst) return a.dst < b.dst;
-      if (a.st != b.st) return a.st < b.st;
-      return a.sq < b.sq;
-    });
+    plap("classify combos, list cells");
+    {
+      // order by (late class, level, dst, st, sq): counting sort on (class, level), then the buckets are sorted
+      // independently on a few host threads (one global std::sort of 27 M cells cost 7 s of every first evaluation)
+      const size_t nbk = (size_t)3 * std::max(S.nlevels, 1);
+      std::vector<size_t> bptr(nbk + 1, 0);
+      for (const Cell& c : cells) bptr[(size_t)c.late * std::max(S.nlevels, 1) + c.level + 1]++;
+      for (size_t k = 0; k < nbk; ++k) bptr[k + 1] += bptr[k];
+      std::vector<Cell> sorted(cells.size());
+      {
+        std::vector<size_t> fill(bptr.begin(), bptr.end() - 1);
+        for (const Cell& c : cells) sorted[fill[(size_t)c.late * std::max(S.nlevels, 1) + c.level]++] = c;
+      }
+      cells.swap(sorted);
+      std::vector<Cell>().swap(sorted);
+      std::atomic<size_t> next{0};
+      auto worker = [&]() {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= nbk) break;
+          std::sort(cells.begin() + bptr[k], cells.begin() + bptr[k + 1], [](const Cell& a, const Cell& b) {
+            if (a.dst != b.dst) return a.dst < b.dst;
+            if (a.st != b.st) return a.st < b.st;
+            return a.sq < b.sq;
+          });
+        }
+      };
+      const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nth; ++t) pool.emplace_back(worker);
+      worker();
+      for (auto& th : pool) th.join();
+    }
     {
       size_t split = 0, split2 = 0;
       while (split < cells.size() && cells[split].late == 0) ++split;
@@ -430,11 +467,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           groups.back().e = (int64_t)i + 1;
         }
         const int64_t long_limit = 16;
-        std::stable_sort(groups.begin(), groups.end(), [&](const Grp& a, const Grp& b) {
-          if (a.level != b.level) return a.level < b.level;
-          const bool la = (a.e - a.b) > long_limit, lb = (b.e - b.b) > long_limit;
-          return la < lb;
-        });
+        // groups arrive ordered by level; inside each level move the short ones to the front (stable, linear)
+        for (size_t g0 = 0; g0 < groups.size();) {
+          size_t g1 = g0;
+          while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
+          std::stable_partition(groups.begin() + g0, groups.begin() + g1,
+                                [&](const Grp& a) { return (a.e - a.b) <= long_limit; });
+          g0 = g1;
+        }
         std::vector<int64_t> udst, grp, st_, sq_;
         std::vector<int32_t> md_, wd_;
         Dev::CellSet& CS = D->cellset[which];
@@ -465,6 +505,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
                 (long long)D->n_dense_combos, (long long)D->n_compact_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
                 (long long)ngroups_total);
       std::vector<Cell>().swap(cells);
+      plap("sort/group/upload cells");
     }
     if (cd.empty()) cd.push_back(ComboDesc{});
     const ComboDesc* dc;
@@ -655,6 +696,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->allocs.push_back(sc);
     D->scratch = (double*)sc;
   }
+  plap("work items, slabs");
   // ---- dense-chain plan for the triangular sweeps
   {
     const int32_t ns = S.nsuper;
@@ -755,6 +797,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       (void)n_ranges;
     }
   }
+  plap("chain sweep plan");
   *out = D;
   return SCILMM_OK;
 }
@@ -809,12 +852,20 @@ struct scilmm_factor {
   double* logd = nullptr;
   int32_t* status = nullptr;
   bool valid = false;
+  bool pending = false;       // a factorization has been queued (scilmm_refactorize_async) and not yet waited for
+  int32_t* h_status = nullptr;  // pinned host copy of *status, filled by the queued copy
 };
 
 namespace {
 
-int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
+int finish_factorize(scilmm_factor* fac, int32_t* bad_col);
+
+int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bool wait = true) {
   scilmm_symbolic* sym = fac->sym;
+  if (fac->pending) {
+    int stp = finish_factorize(fac, nullptr);
+    if (stp != SCILMM_OK && stp != SCILMM_ERR_NOT_PD) return stp;
+  }
   Dev* D = (Dev*)sym->device;
   const Symbolic& S = *sym->S;
   for (int k = 0; k < S.K; ++k)
@@ -1023,8 +1074,22 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   }
   HIPCHK(hipEventRecord(D->ev[2], st));
   HIPCHK(hipGetLastError());
-  int32_t status = 0;
-  HIPCHK(hipMemcpyAsync(&status, fac->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(fac->h_status, fac->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  D->timing.n_launches = launches;
+  fac->pending = true;
+  if (!wait) return SCILMM_OK;
+  return finish_factorize(fac, bad_col);
+}
+
+// second half of a factorization: wait for the queued work, read the event timings and the status word
+int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
+  scilmm_symbolic* sym = fac->sym;
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  hipStream_t st = D->stream;
+  const bool prof = D->profiling;
+  constexpr int PE = 8;
+  fac->pending = false;
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(D->side));
   HIPCHK(hipStreamSynchronize(D->side2));
@@ -1034,7 +1099,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));
   D->timing.assemble_ms = a;
   D->timing.factor_ms = f;
-  D->timing.n_launches = launches;
+  const int32_t status = *fac->h_status;
   if (prof) {
     double tu = 0, tp = 0, tt = 0, tmid = 0;
     int64_t nu = 0;
@@ -1062,6 +1127,37 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
     D->timing.trsm_ms = tt;
     D->timing.reduce_cells_ms = tmid;
     D->timing.n_update_launches = nu;
+    {
+      // union of the update launches' [start, end] intervals, measured from the end of the assembly
+      std::vector<std::pair<float, float>> iv;
+      for (int32_t l = 0; l < S.nlevels; ++l) {
+        float a0 = 0, a1 = 0;
+        if (D->work_ptr[l + 1] > D->work_ptr[l]) {
+          HIPCHK(hipEventElapsedTime(&a0, D->ev[1], D->pev[PE * l + 0]));
+          HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 1]));
+          iv.push_back({a0, a1});
+        }
+        if (D->early_ptr[l + 1] > D->early_ptr[l]) {
+          HIPCHK(hipEventElapsedTime(&a0, D->ev[1], D->pev[PE * l + 5]));
+          HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 6]));
+          iv.push_back({a0, a1});
+        }
+      }
+      std::sort(iv.begin(), iv.end());
+      double uni = 0.0;
+      float cur0 = 0, cur1 = -1;
+      for (auto& q : iv) {
+        if (cur1 < cur0 || q.first > cur1) {
+          if (cur1 >= cur0) uni += cur1 - cur0;
+          cur0 = q.first;
+          cur1 = q.second;
+        } else {
+          cur1 = std::max(cur1, q.second);
+        }
+      }
+      if (cur1 >= cur0) uni += cur1 - cur0;
+      D->timing.update_union_ms = uni;
+    }
     if (const char* dump = getenv("SCILMM_LEVEL_DUMP")) {
       // diagnostic: one line per level (durations in ms; cost = combos + K-chunks of the level's dense work)
       if (FILE* fp = fopen(dump, "w")) {
@@ -1095,6 +1191,10 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
   scilmm_symbolic* sym = fac->sym;
   Dev* D = (Dev*)sym->device;
   const Symbolic& S = *sym->S;
+  if (fac->pending) {
+    int stp = finish_factorize(fac, nullptr);
+    if (stp != SCILMM_OK) return stp;
+  }
   if (!fac->valid) {
     sym->err = "factor is not valid";
     return SCILMM_ERR_STATE;
@@ -1334,6 +1434,7 @@ int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor**
   HIPCHK(hipMemset(f->invD, 0, sizeof(double) * ((size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1) + padI)));
   HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
   HIPCHK(hipMalloc((void**)&f->status, sizeof(int32_t)));
+  HIPCHK(hipHostMalloc((void**)&f->h_status, sizeof(int32_t), hipHostMallocDefault));
   return run_factorize(f, sigma2, bad_col);
 }
 
@@ -1342,8 +1443,21 @@ int scilmm_refactorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_co
   return run_factorize(fac, sigma2, bad_col);
 }
 
+int scilmm_refactorize_async(scilmm_factor* fac, const double* sigma2) {
+  if (!fac || !fac->sym || !sigma2) return SCILMM_ERR_ARG;
+  return run_factorize(fac, sigma2, nullptr, false);
+}
+
+int scilmm_factor_wait(scilmm_factor* fac, int32_t* bad_col) {
+  if (!fac || !fac->sym) return SCILMM_ERR_ARG;
+  if (!fac->pending) return fac->valid ? SCILMM_OK : SCILMM_ERR_STATE;
+  return finish_factorize(fac, bad_col);
+}
+
 void scilmm_factor_free(scilmm_factor* fac) {
   if (!fac) return;
+  if (fac->pending) (void)finish_factorize(fac, nullptr);
+  if (fac->h_status) (void)hipHostFree(fac->h_status);
   if (fac->L) (void)hipFree(fac->L);
   if (fac->invD) (void)hipFree(fac->invD);
   if (fac->logd) (void)hipFree(fac->logd);
@@ -1354,6 +1468,10 @@ void scilmm_factor_free(scilmm_factor* fac) {
 int scilmm_logdet(scilmm_factor* fac, double* out) {
   if (!fac || !fac->sym || !out) return SCILMM_ERR_ARG;
   scilmm_symbolic* sym = fac->sym;
+  if (fac->pending) {
+    int stp = finish_factorize(fac, nullptr);
+    if (stp != SCILMM_OK) return stp;
+  }
   if (!fac->valid) return SCILMM_ERR_STATE;
   Dev* D = (Dev*)sym->device;
   const Symbolic& S = *sym->S;
@@ -1472,6 +1590,10 @@ int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double
   *nnz = total;
   if (!vals) return SCILMM_OK;
   if (!colptr || !rowidx) return SCILMM_ERR_ARG;
+  if (fac->pending) {
+    int stp = finish_factorize(fac, nullptr);
+    if (stp != SCILMM_OK) return stp;
+  }
   if (!fac->valid) return SCILMM_ERR_STATE;
   Dev* D = (Dev*)sym->device;
   std::vector<double> h((size_t)std::max<int64_t>(S.nnzL_stored, 1));

@@ -141,6 +141,17 @@ class Factor(object):
         check(lib().scilmm_refactorize(self._h, ptr(s2), C.byref(bad)), self.sym._h, bad.value)
         return self
 
+    def refactorize_async(self, sigma2):
+        """Queue the refactorization and return; ``wait()`` (or any use of the factor) completes it."""
+        s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
+        check(lib().scilmm_refactorize_async(self._h, ptr(s2)), self.sym._h)
+        return self
+
+    def wait(self):
+        bad = C.c_int32(-1)
+        check(lib().scilmm_factor_wait(self._h, C.byref(bad)), self.sym._h, bad.value)
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:

@@ -178,6 +178,29 @@ def test_factorization_is_bitwise_reproducible():
     assert np.array_equal(L1.data, L2.data) and np.array_equal(L1.indices, L2.indices)
 
 
+def test_async_refactorize_matches_blocking_call():
+    """scilmm_refactorize_async + scilmm_factor_wait (and the implicit wait of every consumer) = scilmm_refactorize."""
+    from scilmm_amd._lib import NotPositiveDefiniteError
+    A, _ = small_pedigree(4000, 0.01, 2)
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    sym = _engine([A, I])
+    f = sym.factorize([0.4, 0.6])
+    f.refactorize([0.7, 0.3])
+    ld, L = f.logdet(), f.L().data.copy()
+    f.refactorize([0.2, 0.9])
+    f.refactorize_async([0.7, 0.3]).wait()
+    assert f.logdet() == ld and np.array_equal(f.L().data, L)
+    f.refactorize([0.2, 0.9])
+    f.refactorize_async([0.7, 0.3])
+    assert f.logdet() == ld  # a consumer completes the queued factorization itself
+    f.refactorize_async([1.0, -5.0])
+    with pytest.raises(NotPositiveDefiniteError):
+        f.wait()
+    f.refactorize([0.7, 0.3])
+    assert f.logdet() == ld
+
+
 def test_compact_update_path_matches_oracle(monkeypatch):
     """Opt-in compact update path (SCILMM_COMPACT=1): same factor as the oracle, and still no float-order races."""
     from oracle import oracle as O
