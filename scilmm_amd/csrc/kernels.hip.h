@@ -1117,21 +1117,43 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
   for (int a = 0; a < NJB; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  // K is streamed in chunks of KCS through single LDS images; the global loads of chunk c+1 are issued into
+  // registers before the MFMAs of chunk c (the launch is latency-bound: one tile per workgroup, ~90 per level)
+  constexpr int PA = KCS / 2, PB = KCS / (256 / NB);  // values per thread and chunk: A row t, B column q
+  const int t = tid & 127, ka = tid >> 7;
+  const int q = tid % NB, kb = tid / NB;
+  const bool ha = t < nrow, hb = q < w;
+  const double* pa = P + R0 + (ha ? t : 0);
+  const double* pb = I + (hb ? q : 0);
+  double ra[PA], rb[PB];
+  auto fetch = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ra[i] = pa[(int64_t)(k0 + min(ka + 2 * i, kc - 1)) * m];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = pb[(int64_t)(k0 + min(kb + (256 / NB) * i, kc - 1)) * w];
+  };
+  auto stage = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = ka + 2 * i;
+      if (k < kc4) As[k * LDA + t] = (ha && k < kc) ? ra[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = kb + (256 / NB) * i;
+      if (k < kc4) Bs[k * LDB + q] = (hb && k < kc) ? rb[i] : 0.0;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
+    }
+  };
+  fetch(0);
   for (int32_t k0 = 0; k0 < w; k0 += KCS) {
     const int kc = min(KCS, w - k0);
     const int kc4 = (kc + 3) & ~3;
-    if (k0 > 0) __syncthreads();
-    for (int idx = tid + kc * LDA; idx < kc4 * LDA; idx += 256) As[idx] = 0.0;
-    for (int idx = tid; idx < kc4 * LDB; idx += 256) Bs[idx] = 0.0;
-    __syncthreads();
-    {
-      const int t = tid & 127;
-      if (t < nrow)
-        for (int k = tid >> 7; k < kc; k += 2) As[k * LDA + t] = P[(int64_t)(k0 + k) * m + R0 + t];
-      const int q = tid % NB;  // Aop[j][k] = invL[j][k] -> Bs[k][j]
-      if (q < w)
-        for (int k = tid / NB; k < kc; k += 256 / NB) Bs[k * LDB + q] = I[(k0 + k) * w + q];
-    }
+    if (k0 > 0) __syncthreads();  // the previous chunk has been consumed
+    stage(k0);
+    if (k0 + KCS < w) fetch(k0 + KCS);
     __syncthreads();
     if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
   }

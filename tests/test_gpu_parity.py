@@ -178,6 +178,18 @@ def test_factorization_is_bitwise_reproducible():
     assert np.array_equal(L1.data, L2.data) and np.array_equal(L1.indices, L2.indices)
 
 
+@pytest.mark.parametrize("env", [{"SCILMM_NO_LOOKAHEAD": "1"}, {"SCILMM_LOOK_DEPTH": "1"}, {"SCILMM_LOOK_DEPTH": "3"},
+                                 {"SCILMM_NO_CHAIN": "1"}, {"SCILMM_UPDATE_VARIANT": "1"}, {"SCILMM_CELL_LIMIT": "64"},
+                                 {"SCILMM_CHAIN_WIDE": "1000", "SCILMM_CHAIN_CAP": "100000"}])
+def test_alternative_schedules_agree_with_oracle(monkeypatch, env):
+    """Every run-time switch selects a different schedule of the SAME arithmetic: all must match the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A, _ = small_pedigree(10000, 0.01, 5)
+    n = A.shape[0]
+    _check_factor([A, sp.identity(n, format="csr")], [0.35, 0.65], _engine([A, sp.identity(n, format="csr")]), rs=(5, 103))
+
+
 def test_async_refactorize_matches_blocking_call():
     """scilmm_refactorize_async + scilmm_factor_wait (and the implicit wait of every consumer) = scilmm_refactorize."""
     from scilmm_amd._lib import NotPositiveDefiniteError
