@@ -937,104 +937,137 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   unsigned long long tprev_ = wall_clock64();
   if (w == NB && tid == 0) atomicAdd(&g_potrf_prof[15], 1ull);
 #endif
-  // lower triangle of the block -> LDS, eight loads in flight per thread
-  for (int base = tid; base < W * W; base += 256 * 8) {
-    double v[8];
+  // lower triangle of the block -> LDS
+  if (w == NB) {
+    // full-width block (every block of a dense chain): constant strides, 32 loads in flight per thread
+    constexpr int PT = NB * NB / 256 / 2;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + 256 * u;
-      const int k = idx / W, i = idx - k * W;
-      v[u] = (i == k) ? 1.0 : 0.0;
-      if (idx < W * W && i < w && k < w && i >= k) v[u] = P[(int64_t)k * m + i];
+    for (int hpass = 0; hpass < 2; ++hpass) {
+      double v[PT];
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        const int idx = tid + 256 * (u + PT * hpass);
+        const int k = idx / NB, i = idx % NB;
+        v[u] = P[(int64_t)k * m + max(i, k)];  // clamped into the lower triangle: unconditional loads
+      }
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        const int idx = tid + 256 * (u + PT * hpass);
+        const int k = idx / NB, i = idx % NB;
+        if (i >= k) F[FA(i, k)] = v[u];
+      }
     }
+  } else {
+    for (int base = tid; base < W * W; base += 256 * 8) {
+      double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + 256 * u;
-      const int k = idx / W, i = idx - k * W;
-      if (idx < W * W && i >= k) F[FA(i, k)] = v[u];
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + 256 * u;
+        const int k = idx / W, i = idx - k * W;
+        v[u] = (i == k) ? 1.0 : 0.0;
+        if (idx < W * W && i < w && k < w && i >= k) v[u] = P[(int64_t)k * m + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + 256 * u;
+        const int k = idx / W, i = idx - k * W;
+        if (idx < W * W && i >= k) F[FA(i, k)] = v[u];
+      }
     }
   }
   __syncthreads();
   PPROF(0);
   const int li = lane & 15, lk = lane >> 4;
-  for (int kb = 0; kb < nb; ++kb) {
+  // One 16 x 16 diagonal block (factor + inverse) is the work of a single wave and the longest step of a block
+  // column, so it runs one column AHEAD: while wave 0 factors block kb+1 (its column was updated first), the
+  // other three waves finish the trailing update of column kb.
+  auto diag16 = [&](int kb) {
     const int o = kb << 4;
     double* Xk = Xd + kb * XS;
-    if (wv == 0) {
-      // ---- 16 x 16 diagonal block in registers, right-looking: lane r (mod 16) owns row r of L; the pivot
-      //      column is broadcast with v_readlane (scalar operands), so a step is one rsqrt + independent FMAs
-      const int r = lane & 15;
-      double a[16], x[16], rs[16];
+    // ---- 16 x 16 diagonal block in registers, right-looking: lane r (mod 16) owns row r of L; the pivot
+    //      column is broadcast with v_readlane (scalar operands), so a step is one rsqrt + independent FMAs
+    const int r = lane & 15;
+    double a[16], x[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? F[FA(o + r, o + c)] : 0.0;
+    for (int c = 0; c < 16; ++c) {
+      a[c] = (c <= r) ? F[FA(o + r, o + c)] : 0.0;
+      x[c] = (c == r) ? 1.0 : 0.0;
+    }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double dj = bc_lane(a[j], j);
-        if (!(dj > 0.0) || !(dj < 1.0e300)) {
-          if (lane == 0) atomicMin(status, c0 + o + j);
-          dj = 1.0;
-        }
-        double y = rsqrt(dj);
-        y = y * (1.5 - 0.5 * dj * y * y);  // one Newton step: full double precision
-        rs[j] = y;
-        const double lj = (r >= j) ? a[j] * y : 0.0;  // L(r, j); the diagonal comes out as dj / sqrt(dj)
-        a[j] = lj;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) a[c] -= lj * bc_lane(lj, c);  // A(r,c) -= L(r,j) L(c,j)  (used for r >= c)
+    for (int j = 0; j < 16; ++j) {
+      double dj = bc_lane(a[j], j);
+      if (!(dj > 0.0) || !(dj < 1.0e300)) {
+        if (lane == 0) atomicMin(status, c0 + o + j);
+        dj = 1.0;
       }
-      // inverse of the block by forward substitution, right-looking: lane r owns COLUMN r of X = L^-1
+      double y = rsqrt(dj);
+      y = y * (1.5 - 0.5 * dj * y * y);  // one Newton step: full double precision
+      const double lj = (r >= j) ? a[j] * y : 0.0;  // L(r, j); the diagonal comes out as dj / sqrt(dj)
+      a[j] = lj;
+      // inverse of the block by forward substitution, right-looking, INTERLEAVED with the factorization (column
+      // j of L is final here): lane r owns COLUMN r of X = L^-1; two independent dependency chains per step
+      x[j] *= y;  // rows above the diagonal stay exactly zero
 #pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        x[j] *= rs[j];  // rows above the diagonal stay exactly zero
-#pragma unroll
-        for (int i = j + 1; i < 16; ++i) x[i] -= bc_lane(a[j], i) * x[j];  // L(i, j) = a[j] in lane i
+      for (int c = j + 1; c < 16; ++c) {
+        const double lcj = bc_lane(lj, c);  // L(c, j)
+        a[c] -= lj * lcj;                   // A(r,c) -= L(r,j) L(c,j)  (used for r >= c)
+        x[c] -= lcj * x[j];
       }
-      if (lane < 16) {
+    }
+    if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c <= r) F[FA(o + r, o + c)] = a[c];  // L(o+r, o+c)
-          Xk[c * 17 + r] = x[c];                   // X(o+c, o+r); zero for c < r
-          if (c >= r && o + c < w && o + r < w) I[(int64_t)(o + r) * w + o + c] = x[c];
-        }
+      for (int c = 0; c < 16; ++c) {
+        if (c <= r) F[FA(o + r, o + c)] = a[c];  // L(o+r, o+c)
+        Xk[c * 17 + r] = x[c];                   // X(o+c, o+r); zero for c < r
+        if (c >= r && o + c < w && o + r < w) I[(int64_t)(o + r) * w + o + c] = x[c];
       }
+    }
+  };
+  auto pair_update = [&](int o, int ib, int kk) {
+    // C_{ib,kk} -= B_ib * B_kk^T (MFMA), lower block pairs
+    const int r0 = o + 16 + 16 * ib, q0 = o + 16 + 16 * kk;
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4 += 4) acc = mfma_f64(F[FA(r0 + li, o + k4 + lk)], F[FA(q0 + li, o + k4 + lk)], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + lk + 4 * r, col = q0 + li;
+      if (row >= col) F[FA(row, col)] -= acc[r];
+    }
+  };
+  if (wv == 0) diag16(0);
+  __syncthreads();
+  PPROF(1);
+  for (int kb = 0; kb + 1 < nb; ++kb) {
+    const int o = kb << 4;
+    const double* Xk = Xd + kb * XS;
+    const int nbr = (W - o - 16) >> 4;
+    // ---- panel below: B_ib = A_ib * Dinv^T, one wave per 16-row block, MFMA, in place
+    //      D[m][n] = sum_k A[m][k] Dinv[n][k];  Dinv[n][k] = X(o+n, o+k) = Xk[n][k]
+    for (int ib = wv; ib < nbr; ib += 4) {
+      const int r0 = o + 16 + 16 * ib;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k4 = 0; k4 < 16; k4 += 4) acc = mfma_f64(F[FA(r0 + li, o + k4 + lk)], Xk[li * 17 + k4 + lk], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) F[FA(r0 + lk + 4 * r, o + li)] = acc[r];
     }
     __syncthreads();
-    PPROF(1);
-    const int nrem = W - o - 16;
-    if (nrem > 0) {
-      const int nbr = nrem >> 4;
-      // ---- panel below: B_ib = A_ib * Dinv^T, one wave per 16-row block, MFMA, in place
-      //      D[m][n] = sum_k A[m][k] Dinv[n][k];  Dinv[n][k] = X(o+n, o+k) = Xk[n][k]
-      for (int ib = wv; ib < nbr; ib += 4) {
-        const int r0 = o + 16 + 16 * ib;
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k4 = 0; k4 < 16; k4 += 4) acc = mfma_f64(F[FA(r0 + li, o + k4 + lk)], Xk[li * 17 + k4 + lk], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) F[FA(r0 + lk + 4 * r, o + li)] = acc[r];
-      }
-      __syncthreads();
-      PPROF(2);
-      // ---- trailing update, lower block pairs (ib >= kk): C_{ib,kk} -= B_ib * B_kk^T (MFMA)
+    PPROF(2);
+    // ---- trailing update, first the next block column (kk = 0) ...
+    for (int ib = wv; ib < nbr; ib += 4) pair_update(o, ib, 0);
+    __syncthreads();
+    // ---- ... then wave 0 factors the next diagonal block while waves 1..3 update the other columns
+    if (wv == 0) {
+      diag16(kb + 1);
+    } else {
       int pidx = 0;
-      for (int ib = 0; ib < nbr; ++ib)
-        for (int kk = 0; kk <= ib; ++kk, ++pidx) {
-          if ((pidx & 3) != wv) continue;
-          const int r0 = o + 16 + 16 * ib, q0 = o + 16 + 16 * kk;
-          d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int k4 = 0; k4 < 16; k4 += 4) acc = mfma_f64(F[FA(r0 + li, o + k4 + lk)], F[FA(q0 + li, o + k4 + lk)], acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = r0 + lk + 4 * r, col = q0 + li;
-            if (row >= col) F[FA(row, col)] -= acc[r];
-          }
-        }
-      __syncthreads();
-      PPROF(3);
+      for (int ib = 1; ib < nbr; ++ib)
+        for (int kk = 1; kk <= ib; ++kk, ++pidx)
+          if (pidx % 3 == wv - 1) pair_update(o, ib, kk);
     }
+    __syncthreads();
+    PPROF(3);
   }
   // ---- inverse, off-diagonal blocks, one block COLUMN per wave (columns j and nb-1-j for balance):
   //      X_ij = -X_ii * sum_{kb=j}^{i-1} L_{i,kb} X_{kb,j}.  An MFMA result block D[(l>>4)+4r][l&15] is, lane by
@@ -1083,9 +1116,17 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
     __syncthreads();
     if (tid == 0) logd[s] = (lgp[0] + lgp[1]) + (lgp[2] + lgp[3]);
   }
-  for (int idx = tid; idx < w * w; idx += 256) {
-    const int k = idx / w, i = idx - k * w;
-    P[(int64_t)k * m + i] = (i >= k) ? F[FA(i, k)] : 0.0;
+  if (w == NB) {
+#pragma unroll 8
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int k = idx / NB, i = idx % NB;
+      P[(int64_t)k * m + i] = (i >= k) ? F[FA(i, k)] : 0.0;
+    }
+  } else {
+    for (int idx = tid; idx < w * w; idx += 256) {
+      const int k = idx / w, i = idx - k * w;
+      P[(int64_t)k * m + i] = (i >= k) ? F[FA(i, k)] : 0.0;
+    }
   }
   PPROF(5);
 #undef FA
