@@ -59,6 +59,8 @@ struct Dev {
   int64_t n_compact_combos = 0;
   hipStream_t side = nullptr;
   hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
+  hipStream_t side3 = nullptr;     // optional third one (SCILMM_SIDE_STREAMS=3)
+  int nside = 2;
   std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
   hipEvent_t ev_asm = nullptr;
   int32_t* d_tile_pslot = nullptr;   // late partial slabs of a tile (main stream)
@@ -154,6 +156,7 @@ void dev_free(void* p) {
   if (D->ev_asm) (void)hipEventDestroy(D->ev_asm);
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->side2) (void)hipStreamDestroy(D->side2);
+  if (D->side3) (void)hipStreamDestroy(D->side3);
   if (D->rest) (void)hipStreamDestroy(D->rest);
   for (auto& e : D->chain_ev)
     if (e) (void)hipEventDestroy(e);
@@ -211,6 +214,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     } else {
       HIPCHK(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, lo));
       HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
+      const char* ens3 = getenv("SCILMM_SIDE_STREAMS");
+      if (ens3 && atoi(ens3) == 3) {
+        HIPCHK(hipStreamCreateWithPriority(&D->side3, hipStreamNonBlocking, lo));
+        D->nside = 3;
+      }
     }
   }
   {
@@ -347,6 +355,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         x.nq = S.upd_p1[e] - S.upd_p0[e];
         x.ip0 = S.combo_ip0[c];
         x.jp0 = S.upd_jp0[e];
+        const bool fake_contig = D->ablate == 3;  // diagnostic: pretend every combo is contiguous (wrong numbers, timing only)
         {
           // spans in target coordinates: rows and columns of a descendant are sorted, so first/last suffice
           const int32_t* rdx = S.sn_rows.data() + x.rowoff;
@@ -355,6 +364,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           x.ihi = (int32_t)(std::lower_bound(lo0, rs + tile_end, rdx[x.ta + x.nt - 1]) - lo0);
           x.jlo = rdx[x.p0] - c0s;
           x.jhi = rdx[x.p0 + x.nq - 1] - c0s;
+        }
+        if (fake_contig) {
+          if (x.ip0 < 0) x.ip0 = std::min<int32_t>(x.ilo, TM - x.nt);
+          if (x.jp0 < 0) x.jp0 = std::min<int32_t>(x.jlo, NB - x.nq);
         }
         if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
           // "late" = the descendant sits one level below the target (finished only just before this level)
@@ -692,7 +705,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->d_tile_pnseg = (int32_t*)tmp;
     void* sc = nullptr;
     // three regions: early slabs by level parity (two side streams), late slabs (main stream)
-    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)3 * (size_t)D->max_slots * TM * NB));
+    HIPCHK(hipMalloc(&sc, sizeof(double) * (size_t)4 * (size_t)D->max_slots * TM * NB));
     D->allocs.push_back(sc);
     D->scratch = (double*)sc;
   }
@@ -910,6 +923,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   HIPCHK(hipEventRecord(D->ev_asm, st));
   HIPCHK(hipStreamWaitEvent(D->side, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->side2, D->ev_asm, 0));
+  if (D->side3) HIPCHK(hipStreamWaitEvent(D->side3, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
   const bool prof = D->profiling;
   constexpr int PE = 8;  // profiling events per level
@@ -961,18 +975,19 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   auto launch_early = [&](int32_t l) -> int {
     const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
     if (!has_early(l)) return SCILMM_OK;
-    hipStream_t sd = (l & 1) ? D->side2 : D->side;
+    const int sidx = l % D->nside;
+    hipStream_t sd = sidx == 0 ? D->side : (sidx == 1 ? D->side2 : D->side3);
     // its youngest descendants sit look_depth + 1 levels below
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
-    if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)(l & 1) * half);
+    if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
     {
       // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
       const int64_t q0 = D->red_ptr_e[l], q1 = D->red_ptr_e[l + 1];
       if (q1 > q0) {
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (q1 - q0))), dim3(128), 0, sd, D->v, D->d_red_tiles_e + q0,
-                           D->d_tile_pslot_e, D->d_tile_pnseg_e, (const double*)(D->scratch + (size_t)(l & 1) * half), fac->L);
+                           D->d_tile_pslot_e, D->d_tile_pnseg_e, (const double*)(D->scratch + (size_t)sidx * half), fac->L);
         launches++;
       }
     }
@@ -988,7 +1003,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   for (int32_t l = 0; l < S.nlevels; ++l) {
     const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
     const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
-    double* sh = D->scratch + (size_t)2 * half;
+    double* sh = D->scratch + (size_t)3 * half;
     // early(l + depth) may start as soon as level l-1 is finished: issue it before this level's own kernels
     if (l >= 1 && l + D->look_depth < S.nlevels) {
       int rc = launch_early(l + D->look_depth);
@@ -1093,6 +1108,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(D->side));
   HIPCHK(hipStreamSynchronize(D->side2));
+  if (D->side3) HIPCHK(hipStreamSynchronize(D->side3));
   HIPCHK(hipStreamSynchronize(D->rest));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
