@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <cmath>
 #include <cstdio>
@@ -318,10 +319,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       }
       if (getenv("SCILMM_VERBOSE")) fprintf(stderr, "[scilmm plan] split candidates: width!=TM %lld, tiles unordered %lld, passed %lld\n", (long long)why[0], (long long)why[1], (long long)why[2]);
     }
-    std::vector<ComboDesc> late_tmp;
     // compact combos, same early | late grouping per tile
     // (each compact combo is cut at tile row TM/2: work item = (tile, half), which owns its cells exclusively)
-    std::vector<ComboDesc> ccd, ctmp[4];                     // ctmp: [half][late]
+    std::vector<ComboDesc> ccd;                              // per tile: [half 0 early | half 0 late | half 1 early | half 1 late]
     std::vector<int64_t> cptr((size_t)4 * ntiles0 + 1, 0);   // segment 4 g + 2 half + late
     // Off by default: measured at the 100k pedigree it takes 10 ms out of the dense kernel (65 -> 55 ms) but the
     // compact items of a level are few (two per tile) and latency-bound (~9 us per combo), so the level sequence
@@ -332,8 +332,20 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const double compact_factor = ecf ? atof(ecf) : 2.0;
     struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };  // late: 0 early, 1 late (main), 2 late (rest stream)
     std::vector<Cell> cells;
-    cd.reserve((size_t)nc / 2 + 16);
-    for (int64_t g = 0; g < ntiles0; ++g) {
+    // The tiles are classified by a few host threads over contiguous tile ranges of about equal combo counts; the
+    // per-range outputs are concatenated in tile order, so the plan does not depend on the thread count.
+    struct Part {
+      std::vector<ComboDesc> cd, ccd;
+      std::vector<int64_t> dend, dmidv, cend;  // per tile: end of its dense list, its early|late split, 4 compact ends
+      std::vector<Cell> cells;
+      int64_t n_sparse = 0, n_compact = 0;
+    };
+    auto process_range = [&](int64_t gbeg, int64_t gend, Part& Pt) {
+    std::vector<ComboDesc>& cd = Pt.cd;
+    std::vector<ComboDesc>& ccd = Pt.ccd;
+    std::vector<Cell>& cells = Pt.cells;
+    std::vector<ComboDesc> late_tmp, ctmp[4];
+    for (int64_t g = gbeg; g < gend; ++g) {
       const int32_t sfr = S.tile_front[g];
       const int32_t ti = (int32_t)(g - S.tile_base[sfr]);
       const int32_t c0s = S.sn_start[sfr];
@@ -396,13 +408,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
               if (x.ip0 >= 0) y.ip0 = x.ip0 + t0;
               ctmp[2 * h + (late ? 1 : 0)].push_back(y);
             }
-            D->n_compact_combos++;
+            Pt.n_compact++;
           } else {
             if (late) late_tmp.push_back(x); else cd.push_back(x);
           }
           continue;
         }
-        D->n_sparse_combos++;
+        Pt.n_sparse++;
         const int32_t* rd = S.sn_rows.data() + x.rowoff;
         const int32_t* lo = rs + R0;
         for (int32_t t = x.ta; t < x.ta + x.nt; ++t) {
@@ -416,95 +428,146 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           }
         }
       }
-      dmid[g] = (int64_t)cd.size();
+      Pt.dmidv.push_back((int64_t)cd.size());
       cd.insert(cd.end(), late_tmp.begin(), late_tmp.end());
       late_tmp.clear();
-      dptr[g + 1] = (int64_t)cd.size();
+      Pt.dend.push_back((int64_t)cd.size());
       for (int k4 = 0; k4 < 4; ++k4) {
         ccd.insert(ccd.end(), ctmp[k4].begin(), ctmp[k4].end());
         ctmp[k4].clear();
-        cptr[4 * g + k4 + 1] = (int64_t)ccd.size();
+        Pt.cend.push_back((int64_t)ccd.size());
+      }
+    }
+    };
+    {
+      const unsigned nth = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), ntiles0));
+      std::vector<int64_t> cut(nth + 1, ntiles0);
+      cut[0] = 0;
+      for (unsigned k = 1; k < nth; ++k) {
+        const int64_t want = nc * (int64_t)k / nth;  // first tile whose combos start at or after this share
+        cut[k] = std::lower_bound(S.combo_ptr.begin(), S.combo_ptr.begin() + ntiles0, want) - S.combo_ptr.begin();
+        cut[k] = std::max(cut[k], cut[k - 1]);
+      }
+      std::vector<Part> parts(nth);
+      std::vector<std::thread> pool;
+      for (unsigned k = 1; k < nth; ++k) pool.emplace_back([&, k]() { process_range(cut[k], cut[k + 1], parts[k]); });
+      process_range(cut[0], cut[1], parts[0]);
+      for (auto& th : pool) th.join();
+      size_t ncd = 0, nccd = 0, ncell = 0;
+      for (auto& Pt : parts) { ncd += Pt.cd.size(); nccd += Pt.ccd.size(); ncell += Pt.cells.size(); }
+      cd.reserve(ncd + 1);
+      ccd.reserve(nccd + 1);
+      cells.reserve(ncell);
+      for (unsigned k = 0; k < nth; ++k) {
+        Part& Pt = parts[k];
+        const int64_t dbase = (int64_t)cd.size(), cbase = (int64_t)ccd.size();
+        for (int64_t g = cut[k]; g < cut[k + 1]; ++g) {
+          dmid[g] = dbase + Pt.dmidv[(size_t)(g - cut[k])];
+          dptr[g + 1] = dbase + Pt.dend[(size_t)(g - cut[k])];
+          for (int k4 = 0; k4 < 4; ++k4) cptr[4 * g + k4 + 1] = cbase + Pt.cend[(size_t)(4 * (g - cut[k]) + k4)];
+        }
+        cd.insert(cd.end(), Pt.cd.begin(), Pt.cd.end());
+        ccd.insert(ccd.end(), Pt.ccd.begin(), Pt.ccd.end());
+        cells.insert(cells.end(), Pt.cells.begin(), Pt.cells.end());
+        D->n_sparse_combos += Pt.n_sparse;
+        D->n_compact_combos += Pt.n_compact;
+        Part().cd.swap(Pt.cd);
+        std::vector<Cell>().swap(Pt.cells);
       }
     }
     D->n_dense_combos = (int64_t)cd.size();
 
     D->n_cells = (int64_t)cells.size();
     plap("classify combos, list cells");
+    size_t split = 0;
+    int64_t ngroups_total = 0;
     {
-      // order by (late class, level, dst, st, sq): counting sort on (class, level), then the buckets are sorted
-      // independently on a few host threads (one global std::sort of 27 M cells cost 7 s of every first evaluation)
-      const size_t nbk = (size_t)3 * std::max(S.nlevels, 1);
+      // Cells are ordered by (late class, level, dst, st, sq): counting sort on (class, level), then every bucket is
+      // sorted, cut into groups of equal target address (short groups first) and written to the upload arrays
+      // independently on a few host threads (one global std::sort of 27 M cells cost 7 s of every first evaluation).
+      const size_t NL = (size_t)std::max(S.nlevels, 1), nbk = 3 * NL;
       std::vector<size_t> bptr(nbk + 1, 0);
-      for (const Cell& c : cells) bptr[(size_t)c.late * std::max(S.nlevels, 1) + c.level + 1]++;
+      for (const Cell& c : cells) bptr[(size_t)c.late * NL + c.level + 1]++;
       for (size_t k = 0; k < nbk; ++k) bptr[k + 1] += bptr[k];
-      std::vector<Cell> sorted(cells.size());
+      split = bptr[NL];
       {
+        std::vector<Cell> sorted(cells.size());
         std::vector<size_t> fill(bptr.begin(), bptr.end() - 1);
-        for (const Cell& c : cells) sorted[fill[(size_t)c.late * std::max(S.nlevels, 1) + c.level]++] = c;
+        for (const Cell& c : cells) sorted[fill[(size_t)c.late * NL + c.level]++] = c;
+        cells.swap(sorted);
       }
-      cells.swap(sorted);
-      std::vector<Cell>().swap(sorted);
-      std::atomic<size_t> next{0};
-      auto worker = [&]() {
-        for (;;) {
-          const size_t k = next.fetch_add(1);
-          if (k >= nbk) break;
-          std::sort(cells.begin() + bptr[k], cells.begin() + bptr[k + 1], [](const Cell& a, const Cell& b) {
-            if (a.dst != b.dst) return a.dst < b.dst;
-            if (a.st != b.st) return a.st < b.st;
-            return a.sq < b.sq;
-          });
-        }
-      };
       const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-      std::vector<std::thread> pool;
-      for (unsigned t = 1; t < nth; ++t) pool.emplace_back(worker);
-      worker();
-      for (auto& th : pool) th.join();
-    }
-    {
-      size_t split = 0, split2 = 0;
-      while (split < cells.size() && cells[split].late == 0) ++split;
-      split2 = split;
-      while (split2 < cells.size() && cells[split2].late == 1) ++split2;
-      int64_t ngroups_total = 0;
+      auto parallel_buckets = [&](const std::function<void(size_t)>& fn) {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+          for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= nbk) break;
+            fn(k);
+          }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nth; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+      };
+      const int64_t long_limit = 16;
+      std::vector<int64_t> g_short(nbk, 0), g_long(nbk, 0), e_short(nbk, 0);
+      parallel_buckets([&](size_t k) {
+        std::sort(cells.begin() + bptr[k], cells.begin() + bptr[k + 1], [](const Cell& a, const Cell& b) {
+          if (a.dst != b.dst) return a.dst < b.dst;
+          if (a.st != b.st) return a.st < b.st;
+          return a.sq < b.sq;
+        });
+        for (size_t i = bptr[k]; i < bptr[k + 1];) {
+          size_t j = i + 1;
+          while (j < bptr[k + 1] && cells[j].dst == cells[i].dst) ++j;
+          if ((int64_t)(j - i) <= long_limit) { g_short[k]++; e_short[k] += (int64_t)(j - i); } else g_long[k]++;
+          i = j;
+        }
+      });
       for (int which = 0; which < 3; ++which) {
-        const size_t cb0 = which == 0 ? 0 : (which == 1 ? split : split2);
-        const size_t ce0 = which == 0 ? split : (which == 1 ? split2 : cells.size());
-        // groups of cells sharing one target address; inside a level the short groups come first
-        struct Grp { int64_t dst, b, e; int32_t level; };
-        std::vector<Grp> groups;
-        for (size_t i = cb0; i < ce0; ++i) {
-          if (i == cb0 || cells[i].dst != cells[i - 1].dst || cells[i].level != cells[i - 1].level)
-            groups.push_back(Grp{cells[i].dst, (int64_t)i, (int64_t)i, cells[i].level});
-          groups.back().e = (int64_t)i + 1;
-        }
-        const int64_t long_limit = 16;
-        // groups arrive ordered by level; inside each level move the short ones to the front (stable, linear)
-        for (size_t g0 = 0; g0 < groups.size();) {
-          size_t g1 = g0;
-          while (g1 < groups.size() && groups[g1].level == groups[g0].level) ++g1;
-          std::stable_partition(groups.begin() + g0, groups.begin() + g1,
-                                [&](const Grp& a) { return (a.e - a.b) <= long_limit; });
-          g0 = g1;
-        }
-        std::vector<int64_t> udst, grp, st_, sq_;
-        std::vector<int32_t> md_, wd_;
         Dev::CellSet& CS = D->cellset[which];
         CS.level_ptr.assign(S.nlevels + 1, 0);
-        CS.level_short.assign(std::max(S.nlevels, 1), 0);
-        for (const Grp& G : groups) {
-          udst.push_back(G.dst);
-          grp.push_back((int64_t)st_.size());
-          CS.level_ptr[G.level + 1]++;
-          if (G.e - G.b <= long_limit) CS.level_short[G.level]++;
-          for (int64_t i = G.b; i < G.e; ++i) {
-            st_.push_back(cells[i].st); sq_.push_back(cells[i].sq); md_.push_back(cells[i].md); wd_.push_back(cells[i].wd);
+        CS.level_short.assign(NL, 0);
+        std::vector<int64_t> gbase(NL + 1, 0), ebase(NL + 1, 0);
+        for (size_t l = 0; l < NL; ++l) {
+          const size_t k = (size_t)which * NL + l;
+          gbase[l + 1] = gbase[l] + g_short[k] + g_long[k];
+          ebase[l + 1] = ebase[l] + (int64_t)(bptr[k + 1] - bptr[k]);
+          if ((int32_t)l < S.nlevels) {
+            CS.level_ptr[l + 1] = gbase[l + 1];
+            CS.level_short[l] = g_short[k];
           }
         }
-        grp.push_back((int64_t)st_.size());
-        for (int32_t l = 0; l < S.nlevels; ++l) CS.level_ptr[l + 1] += CS.level_ptr[l];
-        ngroups_total += (int64_t)groups.size();
+        const int64_t ng = gbase[NL], ne = ebase[NL];
+        std::vector<int64_t> udst((size_t)ng), grp((size_t)ng + 1), st_((size_t)ne), sq_((size_t)ne);
+        std::vector<int32_t> md_((size_t)ne), wd_((size_t)ne);
+        grp[(size_t)ng] = ne;
+        parallel_buckets([&](size_t k) {
+          if (k / NL != (size_t)which) return;
+          const size_t l = k - (size_t)which * NL;
+          // short groups first, then the long ones; both in address order
+          int64_t gs = gbase[l], gl = gbase[l] + g_short[k];
+          int64_t es = ebase[l], el = ebase[l] + e_short[k];
+          for (size_t i = bptr[k]; i < bptr[k + 1];) {
+            size_t j = i + 1;
+            while (j < bptr[k + 1] && cells[j].dst == cells[i].dst) ++j;
+            const bool shortg = (int64_t)(j - i) <= long_limit;
+            int64_t& gi = shortg ? gs : gl;
+            int64_t& ei = shortg ? es : el;
+            udst[(size_t)gi] = cells[i].dst;
+            grp[(size_t)gi] = ei;
+            ++gi;
+            for (size_t c = i; c < j; ++c, ++ei) {
+              st_[(size_t)ei] = cells[c].st; sq_[(size_t)ei] = cells[c].sq; md_[(size_t)ei] = cells[c].md; wd_[(size_t)ei] = cells[c].wd;
+            }
+            i = j;
+          }
+        });
+        ngroups_total += ng;
+        if (udst.empty()) udst.push_back(0);
+        if (st_.empty()) { st_.push_back(0); sq_.push_back(0); md_.push_back(0); wd_.push_back(0); }
         const int64_t* t64; const int32_t* t32;
         if ((st = upload(sym, D, udst, &t64)) != SCILMM_OK) return st; CS.dst = (int64_t*)t64;
         if ((st = upload(sym, D, grp, &t64)) != SCILMM_OK) return st; CS.grp = (int64_t*)t64;
@@ -513,6 +576,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         if ((st = upload(sym, D, md_, &t32)) != SCILMM_OK) return st; CS.md = (int32_t*)t32;
         if ((st = upload(sym, D, wd_, &t32)) != SCILMM_OK) return st; CS.wd = (int32_t*)t32;
       }
+    }
+    {
       if (getenv("SCILMM_VERBOSE"))
         fprintf(stderr, "[scilmm plan] dense combos %lld, compact combos %lld, cell-path combos %lld, cells %lld (early %lld) in %lld target groups\n",
                 (long long)D->n_dense_combos, (long long)D->n_compact_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
