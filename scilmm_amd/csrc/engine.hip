@@ -58,9 +58,12 @@ struct Dev {
   UpdWork* d_cwork_early = nullptr;
   std::vector<int64_t> cwork_ptr, cearly_ptr;  // [nlevels+1]
   int64_t n_compact_combos = 0;
+  int compact_mode = 0;            // 0 off; 1 = (tile, half) items subtract into the panel after the dense kernel;
+                                   // 2 = items write private partial slabs and run BESIDE the dense kernel (folded by k_reduce)
   hipStream_t side = nullptr;
   hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
   hipStream_t side3 = nullptr;     // optional third one (SCILMM_SIDE_STREAMS=3)
+  hipStream_t cside[2] = {nullptr, nullptr};  // compact path: its few long items run beside the next levels' dense updates
   int nside = 2;
   std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
   hipEvent_t ev_asm = nullptr;
@@ -158,6 +161,8 @@ void dev_free(void* p) {
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->side2) (void)hipStreamDestroy(D->side2);
   if (D->side3) (void)hipStreamDestroy(D->side3);
+  for (auto& cs : D->cside)
+    if (cs) (void)hipStreamDestroy(cs);
   if (D->rest) (void)hipStreamDestroy(D->rest);
   for (auto& e : D->chain_ev)
     if (e) (void)hipEventDestroy(e);
@@ -215,6 +220,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     } else {
       HIPCHK(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, lo));
       HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
+      HIPCHK(hipStreamCreateWithPriority(&D->cside[0], hipStreamNonBlocking, lo));
+      HIPCHK(hipStreamCreateWithPriority(&D->cside[1], hipStreamNonBlocking, lo));
       const char* ens3 = getenv("SCILMM_SIDE_STREAMS");
       if (ens3 && atoi(ens3) == 3) {
         HIPCHK(hipStreamCreateWithPriority(&D->side3, hipStreamNonBlocking, lo));
@@ -323,11 +330,15 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // (each compact combo is cut at tile row TM/2: work item = (tile, half), which owns its cells exclusively)
     std::vector<ComboDesc> ccd;                              // per tile: [half 0 early | half 0 late | half 1 early | half 1 late]
     std::vector<int64_t> cptr((size_t)4 * ntiles0 + 1, 0);   // segment 4 g + 2 half + late
-    // Off by default: measured at the 100k pedigree it takes 10 ms out of the dense kernel (65 -> 55 ms) but the
-    // compact items of a level are few (two per tile) and latency-bound (~9 us per combo), so the level sequence
-    // gets longer (factorize 81 -> 98 ms).  Needs finer exclusive ownership or a pipelined item to pay off.
+    // Off by default: measured at the 100k pedigree it takes 10 ms out of the dense kernel (62 -> 52 ms) but a
+    // compact combo costs ~10 us of workgroup time (locate, stage, two barriers per K chunk, scatter) against
+    // ~4 us in the padded dense kernel: mode 1 (two items per tile, after the dense kernel) gives factorize
+    // 66 -> 96 ms, mode 2 (32-combo items with private slabs beside the dense kernel) 66 -> 91 ms.  It needs a
+    // software-pipelined item (several combos in flight) to pay off.
     const char* enoc = getenv("SCILMM_COMPACT");
-    const bool allow_compact = enoc && enoc[0] == '1';
+    const bool allow_compact = enoc && (enoc[0] == '1' || enoc[0] == '2');
+    D->compact_mode = allow_compact ? (enoc[0] == '2' ? 2 : 1) : 0;
+    const bool compact_slabs = D->compact_mode == 2;
     const char* ecf = getenv("SCILMM_COMPACT_FACTOR");
     const double compact_factor = ecf ? atof(ecf) : 2.0;
     struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };  // late: 0 early, 1 late (main), 2 late (rest stream)
@@ -393,9 +404,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           const int64_t bt = (x.nt + 15) >> 4, bq = (x.nq + 15) >> 4;
           const int64_t compact_slots = ksteps * ((bt * bq + 3) / 4) + 24;
           if (allow_compact && bt * bq <= 16 && (double)compact_slots * compact_factor < (double)dense_slots) {
-            // first descendant row that lands at tile position >= TM/2
+            // first descendant row that lands at tile position >= TM/2 (slab mode keeps the combo whole)
             int32_t tsplit = x.nt;
-            if (R0 + TM / 2 < tile_end) {
+            if (!compact_slabs && R0 + TM / 2 < tile_end) {
               const int32_t* rdx = S.sn_rows.data() + x.rowoff + x.ta;
               tsplit = (int32_t)(std::lower_bound(rdx, rdx + x.nt, rs[R0 + TM / 2]) - rdx);
             }
@@ -615,6 +626,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* emi = getenv("SCILMM_MAX_ITEM");
     const char* eti = getenv("SCILMM_TARGET_ITEMS");
     const char* emn = getenv("SCILMM_MIN_ITEM");
+    const char* eci = getenv("SCILMM_COMPACT_ITEM");
+    const int64_t compact_item = std::max<int64_t>(1, eci ? atoll(eci) : 32);  // combos per slab-mode compact item
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -662,28 +675,43 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         const int64_t nl = cut(g, dmid[g], dptr[g + 1], per_l, work);
         // compact items: one per (tile, half, early | late); they run after the dense kernel and the reduce of
         // the same launch sequence and own their cells, so they subtract straight into the panel
-        for (int h = 0; h < 2; ++h) {
-          if (cptr[4 * g + 2 * h + 1] > cptr[4 * g + 2 * h]) cwork_early.push_back(UpdWork{g, h, cptr[4 * g + 2 * h], cptr[4 * g + 2 * h + 1]});
-          if (cptr[4 * g + 2 * h + 2] > cptr[4 * g + 2 * h + 1]) cwork.push_back(UpdWork{g, h, cptr[4 * g + 2 * h + 1], cptr[4 * g + 2 * h + 2]});
+        const size_t cfe = cwork_early.size(), cfl = cwork.size();
+        int64_t nce = 0, ncl = 0;
+        if (!compact_slabs) {
+          for (int h = 0; h < 2; ++h) {
+            if (cptr[4 * g + 2 * h + 1] > cptr[4 * g + 2 * h]) cwork_early.push_back(UpdWork{g, h, cptr[4 * g + 2 * h], cptr[4 * g + 2 * h + 1]});
+            if (cptr[4 * g + 2 * h + 2] > cptr[4 * g + 2 * h + 1]) cwork.push_back(UpdWork{g, h, cptr[4 * g + 2 * h + 1], cptr[4 * g + 2 * h + 2]});
+          }
+        } else {
+          // slab mode: whole combos in segments 0 (early) and 1 (late); items of ~compact_item combos each
+          auto ccut = [&](int64_t cb, int64_t ce, std::vector<UpdWork>& out) -> int64_t {
+            int64_t n = 0;
+            for (int64_t a = cb; a < ce; a += compact_item, ++n) out.push_back(UpdWork{g, 0, a, std::min(ce, a + compact_item)});
+            return n;
+          };
+          nce = ccut(cptr[4 * g], cptr[4 * g + 1], cwork_early);
+          ncl = ccut(cptr[4 * g + 1], cptr[4 * g + 2], cwork);
         }
         // a single dense item of a launch subtracts straight into the panel (the early and the late launch of a
-        // level never overlap in time); two or more go through partial slabs
+        // level never overlap in time); two or more go through partial slabs; slab-mode compact items always do
         const int64_t pe = ne >= 2 ? ne : 0, pl = nl >= 2 ? nl : 0;
         if (ne == 1) work_early[fe].slot = -1;
         if (nl == 1) work[fl].slot = -1;
-        if (pe > 0) {
+        if (pe + nce > 0) {
           pslot_e[g] = (int32_t)slots;
-          pnseg_e[g] = (int32_t)pe;
+          pnseg_e[g] = (int32_t)(pe + nce);
           red_tiles_e.push_back(g);
           for (int64_t k = 0; k < pe; ++k) work_early[fe + k].slot = (int32_t)(slots + k);
-          slots += pe;
+          for (int64_t k = 0; k < nce; ++k) cwork_early[cfe + k].slot = (int32_t)(slots + pe + k);
+          slots += pe + nce;
         }
-        if (pl > 0) {
+        if (pl + ncl > 0) {
           pslot[g] = (int32_t)slots;
-          pnseg[g] = (int32_t)pl;
+          pnseg[g] = (int32_t)(pl + ncl);
           red_tiles.push_back(g);
           for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + k);
-          slots += pl;
+          for (int64_t k = 0; k < ncl; ++k) cwork[cfl + k].slot = (int32_t)(slots + pl + k);
+          slots += pl + ncl;
         }
         if (oi == 0) {  // first tile of the level = the diagonal tile of a split level's front
           D->work_split[l] = (int64_t)work.size() - D->work_ptr[l];
@@ -989,6 +1017,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   HIPCHK(hipStreamWaitEvent(D->side, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->side2, D->ev_asm, 0));
   if (D->side3) HIPCHK(hipStreamWaitEvent(D->side3, D->ev_asm, 0));
+  for (auto& cs : D->cside)
+    if (cs) HIPCHK(hipStreamWaitEvent(cs, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
   const bool prof = D->profiling;
   constexpr int PE = 8;  // profiling events per level
@@ -1013,12 +1043,12 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     launches++;
   };
   const size_t half = (size_t)D->max_slots * TM * NB;
-  auto launch_compact = [&](hipStream_t stream, const UpdWork* cw, int64_t cnt) {
+  auto launch_compact = [&](hipStream_t stream, const UpdWork* cw, int64_t cnt, double* slabs = nullptr) {
     if (cnt <= 0) return;
     if (D->use_mfma)
-      hipLaunchKernelGGL(k_update_compact<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L);
+      hipLaunchKernelGGL(k_update_compact<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L, slabs);
     else
-      hipLaunchKernelGGL(k_update_compact<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L);
+      hipLaunchKernelGGL(k_update_compact<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L, slabs);
     launches++;
   };
   auto launch_cells = [&](hipStream_t stream, int which, int32_t l) {
@@ -1044,9 +1074,21 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     hipStream_t sd = sidx == 0 ? D->side : (sidx == 1 ? D->side2 : D->side3);
     // its youngest descendants sit look_depth + 1 levels below
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
+    const int64_t ncw_e = D->cearly_ptr[l + 1] - D->cearly_ptr[l];
+    const bool slab_compact = D->compact_mode == 2 && ncw_e > 0 && D->cside[l & 1];
+    if (slab_compact) {
+      // the compact items write their own slabs of the same scratch region: they run BESIDE the dense kernel on
+      // their own stream (same dependencies; the region is free once early(l - nside) has been folded)
+      hipStream_t cs = D->cside[l & 1];
+      if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(cs, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
+      if (l >= D->nside) HIPCHK(hipStreamWaitEvent(cs, D->lev_ev[2 * (l - D->nside) + 1], 0));
+      launch_compact(cs, D->d_cwork_early + D->cearly_ptr[l], ncw_e, D->scratch + (size_t)sidx * half);
+      HIPCHK(hipEventRecord(D->chain_ev[3 * l], cs));
+    }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
+    if (slab_compact) HIPCHK(hipStreamWaitEvent(sd, D->chain_ev[3 * l], 0));
     {
       // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
       const int64_t q0 = D->red_ptr_e[l], q1 = D->red_ptr_e[l + 1];
@@ -1056,7 +1098,23 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         launches++;
       }
     }
-    launch_compact(sd, D->d_cwork_early + D->cearly_ptr[l], D->cearly_ptr[l + 1] - D->cearly_ptr[l]);
+    if (D->compact_mode == 2) {
+      launch_cells(sd, 0, l);
+      HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
+      return SCILMM_OK;
+    }
+    if (ncw_e > 0 && D->cside[l & 1]) {
+      // compact items (few, long) and the cells of the level move to their own stream: the side stream goes on
+      // with the dense update of the level after next while they run (same panels: ordered by the event)
+      hipStream_t cs = D->cside[l & 1];
+      HIPCHK(hipEventRecord(D->chain_ev[3 * l], sd));
+      HIPCHK(hipStreamWaitEvent(cs, D->chain_ev[3 * l], 0));
+      launch_compact(cs, D->d_cwork_early + D->cearly_ptr[l], ncw_e);
+      launch_cells(cs, 0, l);
+      HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], cs));
+      return SCILMM_OK;
+    }
+    launch_compact(sd, D->d_cwork_early + D->cearly_ptr[l], ncw_e);
     launch_cells(sd, 0, l);  // early cells: same stream, after the early MFMA update of the same panels
     HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
     return SCILMM_OK;
@@ -1097,9 +1155,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       if (prev_split) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - 1)], 0));
       if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
       if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+      if (D->compact_mode == 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l], sh);
       if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
       launch_reduce(st, r0, r1);
-      launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
+      if (D->compact_mode != 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
       launch_cells(st, 1, l);
       if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
       if (f1 > f0) {
@@ -1175,6 +1234,8 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   HIPCHK(hipStreamSynchronize(D->side2));
   if (D->side3) HIPCHK(hipStreamSynchronize(D->side3));
   HIPCHK(hipStreamSynchronize(D->rest));
+  for (auto& cs : D->cside)
+    if (cs) HIPCHK(hipStreamSynchronize(cs));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));

@@ -656,7 +656,10 @@ constexpr int KCQ = 16;  // K depth per staging chunk of the compact path
 
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_update_compact(DevSym S, const UpdWork* __restrict__ work,
-                                                        const ComboDesc* __restrict__ combos, double* __restrict__ L) {
+                                                        const ComboDesc* __restrict__ combos, double* __restrict__ L,
+                                                        double* __restrict__ slabs) {
+  // slabs == nullptr: the item owns its half tile and subtracts from the panel.  Otherwise it accumulates into
+  // its private partial slab slabs[slot] (zeroed here; k_reduce folds it) and may run beside other writers.
   __shared__ __attribute__((aligned(16))) double As[KCQ * LDA];  // [k][t]  descendant rows of the tile (compact)
   __shared__ __attribute__((aligned(16))) double Bs[KCQ * LDB];  // [k][q]  descendant rows = target columns (compact)
   __shared__ int32_t rowlab[TM];
@@ -673,8 +676,13 @@ __global__ __launch_bounds__(256) void k_update_compact(DevSym S, const UpdWork*
   const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
   const int32_t R0 = ti * TM;
   const int32_t nrow = min(TM, m - R0);
-  double* Q = L + S.sn_loff[s] + R0;  // cell (tile position i, target column j) at Q[j * m + i]
+  double* Q = slabs ? slabs + (int64_t)wk.slot * (TM * NB) : L + S.sn_loff[s] + R0;  // cell (i, j) at Q[j * ldq + i]
+  const int64_t ldq = slabs ? TM : m;
+  const double sgn = slabs ? 1.0 : -1.0;
+  if (slabs)
+    for (int idx = tid; idx < TM * NB; idx += 256) Q[idx] = 0.0;
   if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab zeros are in L2 before the first atomic of this item
   __syncthreads();
   for (int64_t c = wk.cb; c < wk.ce; ++c) {
     const ComboDesc d = combos[c];
@@ -757,7 +765,7 @@ __global__ __launch_bounds__(256) void k_update_compact(DevSym S, const UpdWork*
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = 16 * jb + lk + 4 * r;
-          if (t < d.nt && q < d.nq) unsafeAtomicAdd(&Q[(int64_t)col[q] * m + pos[t]], -acc[a][r]);
+          if (t < d.nt && q < d.nq) unsafeAtomicAdd(&Q[(int64_t)col[q] * ldq + pos[t]], sgn * acc[a][r]);
         }
       }
     }

@@ -213,10 +213,12 @@ def test_async_refactorize_matches_blocking_call():
     assert f.logdet() == ld
 
 
-def test_compact_update_path_matches_oracle(monkeypatch):
-    """Opt-in compact update path (SCILMM_COMPACT=1): same factor as the oracle, and still no float-order races."""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_compact_update_path_matches_oracle(monkeypatch, mode):
+    """Opt-in compact update path (SCILMM_COMPACT=1: into the panel, 2: via partial slabs): same factor as the
+    oracle, and still no float-order races."""
     from oracle import oracle as O
-    monkeypatch.setenv("SCILMM_COMPACT", "1")
+    monkeypatch.setenv("SCILMM_COMPACT", mode)
     A, _ = small_pedigree(10000, 0.01, 0)
     n = A.shape[0]
     sym = _engine([A, sp.identity(n, format="csr")])
