@@ -114,6 +114,11 @@ struct Dev {
   int64_t* d_cg_ptr = nullptr;     // backward: pairs (chain target, non-chain descendant) grouped by descendant
   int32_t* d_cg_pairs = nullptr;
   int64_t chain_groups = 0;
+  // long groups are cut into row slices that write partial sums; k_push_fold adds them up in fixed order
+  int32_t* d_cg_slot = nullptr;      // per work item: partial slot or -1 (subtract straight from X)
+  int32_t* d_fold = nullptr;         // triples (descendant, first slot, slices)
+  int64_t n_fold = 0;
+  double* d_push_partial = nullptr;  // [slots][NB][RPMAX]
   int32_t* d_chain_flags = nullptr;  // [chain_T * RPMAX/CW] epoch stamps
   int32_t* d_chain_err = nullptr;
   int32_t chain_epoch = 0;
@@ -877,8 +882,69 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           gpairs.push_back(S.upd_p1[e]);
         }
       }
-      D->chain_groups = (int64_t)gptr.size();
       gptr.push_back((int64_t)gpairs.size() / 3);
+      std::vector<int32_t> gslot, fold;
+      {
+        // one workgroup sweeps its rows 32 at a time (~3.5 us per step): a descendant with 10^4 rows in the chain
+        // would take a millisecond alone, so long groups are cut into slices of <= slice_rows rows
+        const char* esr = getenv("SCILMM_PUSH_SLICE");
+        const int64_t slice_rows = std::max<int64_t>(256, esr ? atoll(esr) : 512);
+        std::vector<int64_t> gptr2;
+        std::vector<int32_t> gp2;
+        int32_t nslots = 0;
+        for (size_t g = 0; g + 1 < gptr.size(); ++g) {
+          int64_t rows = 0;
+          for (int64_t q = gptr[g]; q < gptr[g + 1]; ++q) rows += gpairs[3 * q + 2] - gpairs[3 * q + 1];
+          const int64_t nsl = (rows + slice_rows - 1) / slice_rows;
+          if (nsl <= 1) {
+            gptr2.push_back((int64_t)gp2.size() / 3);
+            gp2.insert(gp2.end(), gpairs.begin() + 3 * gptr[g], gpairs.begin() + 3 * gptr[g + 1]);
+            gslot.push_back(-1);
+            continue;
+          }
+          const int64_t per = (rows + nsl - 1) / nsl;
+          fold.push_back(gpairs[3 * gptr[g]]);
+          fold.push_back(nslots);
+          int32_t made = 0;
+          int64_t acc = 0;
+          gptr2.push_back((int64_t)gp2.size() / 3);
+          gslot.push_back(nslots + made);
+          ++made;
+          for (int64_t q = gptr[g]; q < gptr[g + 1]; ++q) {
+            int32_t a = gpairs[3 * q + 1];
+            const int32_t b = gpairs[3 * q + 2];
+            while (a < b) {
+              if (acc == per) {  // start the next slice
+                gptr2.push_back((int64_t)gp2.size() / 3);
+                gslot.push_back(nslots + made);
+                ++made;
+                acc = 0;
+              }
+              const int32_t take = (int32_t)std::min<int64_t>(b - a, per - acc);
+              gp2.push_back(gpairs[3 * q]);
+              gp2.push_back(a);
+              gp2.push_back(a + take);
+              a += take;
+              acc += take;
+            }
+          }
+          fold.push_back(made);
+          nslots += made;
+        }
+        gptr2.push_back((int64_t)gp2.size() / 3);
+        gptr.swap(gptr2);
+        gpairs.swap(gp2);
+        D->n_fold = (int64_t)fold.size() / 3;
+        if (nslots > 0) {
+          void* pp = nullptr;
+          HIPCHK(hipMalloc(&pp, sizeof(double) * (size_t)nslots * NB * RPMAX));
+          D->allocs.push_back(pp);
+          D->d_push_partial = (double*)pp;
+        }
+        if (fold.empty()) fold.assign(3, 0);
+        if (gslot.empty()) gslot.push_back(-1);
+      }
+      D->chain_groups = (int64_t)gptr.size() - 1;
       const int32_t* t32; const int64_t* t64; const ChainPair* tcp;
       if (fl.empty()) fl.push_back(ChainPair{0, 0, 0, 0, 0});
       if (bl.empty()) bl.push_back(ChainPair{0, 0, 0, 0, 0});
@@ -893,6 +959,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if ((st = upload(sym, D, bl, &tcp)) != SCILMM_OK) return st; D->d_cb = (ChainPair*)tcp;
       if ((st = upload(sym, D, gptr, &t64)) != SCILMM_OK) return st; D->d_cg_ptr = (int64_t*)t64;
       if ((st = upload(sym, D, gpairs, &t32)) != SCILMM_OK) return st; D->d_cg_pairs = (int32_t*)t32;
+      if ((st = upload(sym, D, gslot, &t32)) != SCILMM_OK) return st; D->d_cg_slot = (int32_t*)t32;
+      if ((st = upload(sym, D, fold, &t32)) != SCILMM_OK) return st; D->d_fold = (int32_t*)t32;
       std::vector<int32_t> zeros((size_t)T * (RPMAX / CW) + 1, 0);
       if ((st = upload(sym, D, zeros, &t32)) != SCILMM_OK) return st;
       D->d_chain_flags = (int32_t*)t32;
@@ -1415,10 +1483,15 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         if (D->chain_groups > 0) {
           if (mf)
             hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)D->chain_groups, gy), dim3(256), 0, st, D->v,
-                               (const int32_t*)D->d_cg_pairs, (const int64_t*)D->d_cg_ptr, fac->L, D->X, rp);
+                               (const int32_t*)D->d_cg_pairs, (const int64_t*)D->d_cg_ptr, fac->L, D->X, rp,
+                               (const int32_t*)D->d_cg_slot, D->d_push_partial);
           else
             hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)D->chain_groups, gy), dim3(256), 0, st, D->v,
-                               (const int32_t*)D->d_cg_pairs, (const int64_t*)D->d_cg_ptr, fac->L, D->X, rp);
+                               (const int32_t*)D->d_cg_pairs, (const int64_t*)D->d_cg_ptr, fac->L, D->X, rp,
+                               (const int32_t*)D->d_cg_slot, D->d_push_partial);
+          if (D->n_fold > 0)
+            hipLaunchKernelGGL(k_push_fold, dim3((unsigned)D->n_fold, gy), dim3(256), 0, st, D->v, (const int32_t*)D->d_fold,
+                               (const double*)D->d_push_partial, D->X, rp);
         }
       }
       for (int32_t l = lend - 1; l >= 0; --l) {
@@ -1435,10 +1508,10 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
         if (p1 > p0) {
           if (mf)
             hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
-                               (const int64_t*)nullptr, fac->L, D->X, rp);
+                               (const int64_t*)nullptr, fac->L, D->X, rp, (const int32_t*)nullptr, (double*)nullptr);
           else
             hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
-                               (const int64_t*)nullptr, fac->L, D->X, rp);
+                               (const int64_t*)nullptr, fac->L, D->X, rp, (const int32_t*)nullptr, (double*)nullptr);
         }
       }
       hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);

@@ -1424,7 +1424,8 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __restrict__ pairs,
                                                   const int64_t* __restrict__ grp_ptr, const double* __restrict__ L,
-                                                  double* __restrict__ X, int32_t rp) {
+                                                  double* __restrict__ X, int32_t rp, const int32_t* __restrict__ grp_slot,
+                                                  double* __restrict__ partial) {
   // grp_ptr == nullptr: one update pair per workgroup.  Otherwise `pairs` holds triples (descendant, p0, p1) and
   // workgroup b folds the row ranges [grp_ptr[b], grp_ptr[b+1]) -- all of the SAME descendant d -- into one
   // read-modify-write of X[cols of d] (used after the chain sweep, where the targets of many levels are final at
@@ -1438,6 +1439,7 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
   const int64_t g0 = grp_ptr ? grp_ptr[blockIdx.x] : (int64_t)blockIdx.x;
   const int64_t g1 = grp_ptr ? grp_ptr[blockIdx.x + 1] : (int64_t)blockIdx.x + 1;
   const int32_t d = grp_ptr ? pairs[3 * g0] : S.upd_src[pairs[g0]];
+  const int32_t pslot = grp_slot ? grp_slot[blockIdx.x] : -1;
   const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
   const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
   const int32_t cd = S.sn_start[d], wd = S.sn_start[d + 1] - cd;
@@ -1504,13 +1506,33 @@ __global__ __launch_bounds__(256) void k_bwd_push(DevSym S, const int32_t* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int k = 16 * kb + lr + 4 * r;
-              if (k < wd) X[(int64_t)(cd + k) * rp + c_lo + 16 * cn + li] -= acc[h][cn][r];
+              if (k < wd) {
+                // a row slice of a long group leaves its partial sum for k_push_fold (fixed summation order)
+                if (pslot >= 0) partial[((int64_t)pslot * NB + k) * rp + c_lo + 16 * cn + li] = acc[h][cn][r];
+                else X[(int64_t)(cd + k) * rp + c_lo + 16 * cn + li] -= acc[h][cn][r];
+              }
             }
       }
     }
   }
 }
 
+
+// X[cols of d] -= sum of the partial sums the row slices of a long group left (slices in order)
+__global__ __launch_bounds__(256) void k_push_fold(DevSym S, const int32_t* __restrict__ fold, const double* __restrict__ partial,
+                                                   double* __restrict__ X, int32_t rp) {
+  const int32_t d = fold[3 * blockIdx.x], slot0 = fold[3 * blockIdx.x + 1], ns = fold[3 * blockIdx.x + 2];
+  const int c_lo = blockIdx.y * CW;
+  const int rpl = min(CW, rp - c_lo);
+  const int32_t cd = S.sn_start[d], wd = S.sn_start[d + 1] - cd;
+  const int cc = threadIdx.x % CW;
+  if (cc >= rpl) return;
+  for (int k = threadIdx.x / CW; k < wd; k += 256 / CW) {
+    double sum = 0.0;
+    for (int sl = 0; sl < ns; ++sl) sum += partial[((int64_t)(slot0 + sl) * NB + k) * rp + c_lo + cc];
+    X[(int64_t)(cd + k) * rp + c_lo + cc] -= sum;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Dense-chain sweeps.  The last levels of the elimination tree are a chain of single fronts (the blocks of
