@@ -1383,15 +1383,28 @@ __global__ __launch_bounds__(256) void k_fwd(DevSym S, const int32_t* __restrict
     a0[cn] = (d4){0.0, 0.0, 0.0, 0.0};
     a1[cn] = (d4){0.0, 0.0, 0.0, 0.0};
   }
+  // panel chunk c+1 is fetched into registers before the MFMAs of chunk c (same staging as k_trsm)
+  constexpr int PA = KCS / 2;
+  const int ta_ = tid & 127, ka_ = tid >> 7;
+  const bool ha_ = ta_ < nrow;
+  const double* pa_ = P + R0 + (ha_ ? ta_ : 0);
+  double ra_[PA];
+  auto fetch = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ra_[i] = pa_[(int64_t)(k0 + min(ka_ + 2 * i, kc - 1)) * m];
+  };
+  fetch(0);
   for (int32_t k0 = 0; k0 < w; k0 += KCS) {
     const int kc = min(KCS, w - k0);
     const int kc4 = (kc + 3) & ~3;
     if (k0 > 0) __syncthreads();
-    {
-      const int t = tid & 127;
-      for (int k = tid >> 7; k < kc4; k += 2)
-        As[k * LDA + t] = (t < nrow && k < kc) ? P[(int64_t)(k0 + k) * m + R0 + t] : 0.0;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = ka_ + 2 * i;
+      if (k < kc4) As[k * LDA + ta_] = (ha_ && k < kc) ? ra_[i] : 0.0;
     }
+    if (k0 + KCS < w) fetch(k0 + KCS);
     __syncthreads();
     if (32 * wv < nrow) {
       rhs_mma<MFMA, NCT>(As, LDA, 32 * wv, Ys + k0 * LDW, LDW, kc4, ncn, lane, a0);
