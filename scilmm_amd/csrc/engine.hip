@@ -1870,3 +1870,10 @@ extern "C" int scilmm_debug_potrf_prof(unsigned long long* out16, int reset) {
   return 0;
 }
 #endif
+
+#ifdef SCILMM_CHAIN_PROF
+extern "C" int scilmm_debug_chain_prof(unsigned long long* out, int n) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scilmm::g_chain_prof), sizeof(unsigned long long) * 8 * (size_t)n) != hipSuccess) return -3;
+  return 0;
+}
+#endif

@@ -1583,11 +1583,15 @@ __device__ __forceinline__ double ld_off(const double* base, uint32_t voff8) {
 }
 __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ bool chain_wait(const int32_t* flag, int32_t epoch, int32_t* err) {
-  // one thread spins; returns false on timeout / earlier error (the caller then leaves quietly)
+__device__ __forceinline__ bool chain_wait(const int32_t* flag, int32_t epoch, int32_t* err, int behind) {
+  // one thread spins; returns false on timeout / earlier error (the caller then leaves quietly).  `behind` = how
+  // many more blocks this workgroup has to wait for after this one: only the workgroups next in line poll
+  // tightly, the others mostly sleep (a few hundred pollers on two dozen flag lines slow every hop down)
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-    __builtin_amdgcn_s_sleep(1);
+    if (behind == 0) __builtin_amdgcn_s_sleep(1);
+    else
+      for (int z = 0; z < min(behind, 8); ++z) __builtin_amdgcn_s_sleep(127);
     if ((++spins & 1023) == 0) {
       if (spins > (1 << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1600,6 +1604,12 @@ __device__ __forceinline__ bool chain_wait(const int32_t* flag, int32_t epoch, i
 
 #ifndef SCILMM_CHAIN_WAVES
 #define SCILMM_CHAIN_WAVES 2
+#endif
+#ifdef SCILMM_CHAIN_PROF
+__device__ unsigned long long g_chain_prof[8 * 4096];  // per front (window 0, forward sweep): eight timestamps
+#define CPROF(slot) do { if (c == 0 && tid == 0 && i < 4096 && !BWD) g_chain_prof[8 * i + (slot)] = wall_clock64(); } while (0)
+#else
+#define CPROF(slot) do {} while (0)
 #endif
 template <bool MFMA, bool BWD>
 __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int32_t T, const int32_t* __restrict__ chain,
@@ -1717,7 +1727,8 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
     const int kvalid = BWD ? pr.nq : wo;
     if (e == e1 - 1) load_iv();
     if (e - e0 >= nready) {
-      if (tid == 0) s_ok = chain_wait(flags + (int64_t)pr.other * ncw + c, epoch, err) ? 1 : 0;
+      if (tid == 0) s_ok = chain_wait(flags + (int64_t)pr.other * ncw + c, epoch, err, e1 - 1 - e) ? 1 : 0;
+      if (e == e1 - 1) CPROF(0);  // flag of the newest block observed
       __syncthreads();
       ok = s_ok != 0;
     }
@@ -1740,6 +1751,7 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
         }
     }
     __syncthreads();
+    if (e == e1 - 1) CPROF(1);  // x window staged
     if (ok) {
       if (MFMA) {
 #pragma unroll
@@ -1773,6 +1785,7 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
       }
     }
     __syncthreads();  // Ys is reused by the next pair
+    if (e == e1 - 1) CPROF(2);  // last pair multiplied
   };
   if (e0 == e1) load_iv();
   for (int32_t e = e0; e < e1 && ok; ++e) {
@@ -1791,6 +1804,7 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
       }
   }
   __syncthreads();
+  CPROF(3);  // w_i in LDS
   if (ok && 16 * wv < w) {
     d4 xa[NCT];
 #pragma unroll
@@ -1825,8 +1839,10 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
             __hip_atomic_store(&X[(int64_t)(c0 + jr) * rp + c_lo + 16 * cn + li], xa[cn][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
   }
+  CPROF(4);  // wave 0: diagonal product done, stores issued
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
   __syncthreads();
+  CPROF(5);  // all waves drained
   if (tid == 0 && ok) __hip_atomic_store(flags + (int64_t)i * ncw + c, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
