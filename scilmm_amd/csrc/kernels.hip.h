@@ -1738,17 +1738,27 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
       // and a 128-byte line never holds data of two producers (windows are 256-byte aligned).
       const int nx = BWD ? pr.nq : wo;
       const int cc = tid & 63;
-      if (cc < LDW)
-        for (int k = tid >> 6; k < kn; k += 8) {
-          double v = 0.0;
+      if (cc < LDW) {
+        // all rows of this thread are requested before the first one is written to LDS (the loop form waited
+        // for every load in turn: 16 exposed latencies on the critical path of the sweep)
+        double xv[NB / 8];
+#pragma unroll
+        for (int u = 0; u < NB / 8; ++u) {
+          const int k = (tid >> 6) + 8 * u;
+          xv[u] = 0.0;
           if (k < nx && cc < rpl) {
             int64_t xr;
             if (!BWD) xr = co + k;
             else xr = (pr.jp0 >= 0) ? co + pr.jp0 + k : S.sn_rows[S.sn_rowptr[s] + pr.p0 + k];
-            v = X[xr * rp + c_lo + cc];
+            xv[u] = X[xr * rp + c_lo + cc];
           }
-          Ys[k * LDW + cc] = v;
         }
+#pragma unroll
+        for (int u = 0; u < NB / 8; ++u) {
+          const int k = (tid >> 6) + 8 * u;
+          if (k < kn) Ys[k * LDW + cc] = xv[u];
+        }
+      }
     }
     __syncthreads();
     if (e == e1 - 1) CPROF(1);  // x window staged
