@@ -36,6 +36,31 @@ __global__ __launch_bounds__(256) void k_fma(double* out, int iters, double a0, 
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Do the matrix pipe and the vector ALU overlap?  Same two kernels on two streams at once.
+static void both(double* d, int iters) {
+  hipStream_t s0, s1;
+  hipStreamCreateWithFlags(&s0, hipStreamNonBlocking);
+  hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+  hipEvent_t e0, e1, e2;
+  hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipDeviceSynchronize();
+    hipEventRecord(e0, s0);
+    hipStreamWaitEvent(s1, e0, 0);
+    hipLaunchKernelGGL(k_mfma<8>, dim3(256 * 4), dim3(256), 0, s0, d, iters, 1.0, 1e-3);
+    hipLaunchKernelGGL(k_fma, dim3(256 * 4), dim3(256), 0, s1, d + 256 * 2048, iters, 1.0000001, 1e-3);
+    hipEventRecord(e1, s0);
+    hipEventRecord(e2, s1);
+    hipEventSynchronize(e1); hipEventSynchronize(e2);
+    float m0, m1;
+    hipEventElapsedTime(&m0, e0, e1);
+    hipEventElapsedTime(&m1, e0, e2);
+    const double fm = 256.0 * 4 * 4 * iters * 8 * 2048.0, fv = 256.0 * 4 * 256 * iters * 16 * 2.0;
+    if (rep) printf("concurrent: mfma kernel %.3f ms, fma kernel %.3f ms -> %.1f TF combined over the longer one\n", m0, m1,
+                    (fm + fv) / (m0 > m1 ? m0 : m1) / 1e9);
+  }
+}
+
 int main() {
   double* d;
   (void)hipMalloc(&d, sizeof(double) * 256 * 4096);
@@ -43,6 +68,7 @@ int main() {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 20000;
+  both(d, iters);
   for (int wgs_per_cu = 1; wgs_per_cu <= 8; wgs_per_cu *= 2) {
     int grid = 256 * wgs_per_cu;
     for (int rep = 0; rep < 2; ++rep) {
