@@ -1,5 +1,6 @@
-// Hand-written CDNA4 (gfx950) kernels of the numeric phase.  Wave = 64 lanes; 256-thread workgroups
-// (one wave per SIMD); fp64 MFMA v_mfma_f64_16x16x4_f64 for every GEMM-shaped step.
+// Hand-written CDNA4 (gfx950) kernels of the numeric phase.  Wave = 64 lanes; 256-thread workgroups (one
+// wave per SIMD) except the update and chain-sweep kernels (512 threads, two waves per SIMD: a single wave
+// cannot keep the fp64 matrix pipe busy); fp64 MFMA v_mfma_f64_16x16x4_f64 for every GEMM-shaped step.
 //
 // Data layout in HBM:
 //   L        : supernodal panels, column-major m_s x w_s, leading dimension m_s, at sn_loff[s]
@@ -13,7 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #ifndef SCILMM_KC
-#define SCILMM_KC 32
+#define SCILMM_KC 16
 #endif
 #ifndef SCILMM_NB
 #define SCILMM_NB 128
@@ -31,7 +32,7 @@ constexpr int NB = SCILMM_NB; // max supernode block width (symbolic max_width m
 constexpr int NJB = NB / 16;  // 16-column MFMA tiles across a block
 constexpr int TM = 128;       // target rows per tile
 constexpr int KCS = 16;       // k-chunk of the trsm / solve kernels
-constexpr int KC = SCILMM_KC;        // k-chunk staged through LDS (update kernel: 2 x 28 KB -> two workgroups per CU)
+constexpr int KC = SCILMM_KC;  // k-chunk of the update kernel: 2 buffers x 16 x (144 + 144) doubles = 74 KB -> two workgroups per CU
 constexpr int LDA = TM + 16;  // k-major LDS leading dims: (ld*8 B) == 128 mod 256 -> conflict-free b64 reads
 constexpr int LDB = NB + 16;
 constexpr int RPMAX = 128;    // max padded RHS columns per pass
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym
   const int ncb = (w + 15) >> 4;
   if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
   for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
-  // eight waves: wave wv owns target rows [16 wv, 16 wv + 16) and all 64 columns (4 accumulator tiles)
+  // eight waves: wave wv owns target rows [16 wv, 16 wv + 16) and all NB columns (NJB accumulator tiles)
   d4 acc[NJB];
 #pragma unroll
   for (int a = 0; a < NJB; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -903,11 +904,12 @@ __global__ __launch_bounds__(128) void k_reduce(DevSym S, const int32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense Cholesky of the w x w (w <= 64) diagonal block of each front of a level plus its explicit
+// Dense Cholesky of the w x w (w <= NB) diagonal block of each front of a level plus its explicit
 // inverse (every later triangular solve with this block becomes an MFMA GEMM) and sum(log diag).
-// Blocked by 16: the 16 x 16 diagonal blocks are factored and inverted by ONE wave in registers with
-// cross-lane shuffles (no barriers); panel solve, trailing update and the block recursion for the
-// inverse run on all 256 threads out of LDS.  ~30 barriers instead of ~200 + a 2000-step serial loop.
+// Blocked by 16: the 16 x 16 diagonal blocks are factored and inverted by ONE wave in registers (pivot column
+// broadcast with v_readlane, factor and inverse steps interleaved), one block column AHEAD of the trailing
+// update the other three waves are finishing; panel solve and trailing update are MFMA products out of the
+// folded LDS triangle; the off-diagonal blocks of the inverse stay in registers (block column per wave).
 // value of x in lane `src` (wave-uniform src) as a scalar broadcast: two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double bc_lane(double x, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
