@@ -18,6 +18,7 @@
 
 #include "../../include/scilmm_hip.h"
 #include "kernels.hip.h"
+#include "cellplan.hip.h"
 #include "handles.h"
 
 using namespace scilmm;
@@ -173,6 +174,180 @@ void dev_free(void* p) {
     if (e) (void)hipEventDestroy(e);
   if (D->stream) (void)hipStreamDestroy(D->stream);
   delete D;
+}
+
+// Expand the small combos to the cell lists of k_sparse_cells on the device (see cellplan.hip.h).
+int build_cells_device(scilmm_symbolic* sym, Dev* D, const std::vector<CellCombo>& cc, int32_t NL, int64_t* ngroups_total,
+                       int64_t* n_early) {
+  const Symbolic& S = *sym->S;
+  const int64_t ncc = (int64_t)cc.size();
+  std::vector<int64_t> off((size_t)ncc + 1, 0);
+  for (int64_t c = 0; c < ncc; ++c) off[(size_t)c + 1] = off[(size_t)c] + (int64_t)cc[(size_t)c].nt * cc[(size_t)c].nq;
+  const int64_t total = off[(size_t)ncc];
+  auto dmalloc = [&](void** p, size_t bytes) -> int {
+    HIPCHK(hipMalloc(p, std::max<size_t>(bytes, 8)));
+    return SCILMM_OK;
+  };
+  int st;
+  std::vector<void*> tmp;  // freed on exit
+  auto tmalloc = [&](void** p, size_t bytes) -> int {
+    int r = dmalloc(p, bytes);
+    if (r == SCILMM_OK) tmp.push_back(*p);
+    return r;
+  };
+  struct Cleanup {
+    std::vector<void*>& v;
+    ~Cleanup() { for (void* p : v) (void)hipFree(p); }
+  } cleanup{tmp};
+  for (int c = 0; c < 3; ++c) {
+    D->cellset[c].level_ptr.assign(S.nlevels + 1, 0);
+    D->cellset[c].level_short.assign(std::max<int32_t>(NL, 1), 0);
+  }
+  *ngroups_total = 0;
+  *n_early = 0;
+  D->n_cells = 0;
+  if (total == 0) {
+    void* d8 = nullptr;
+    if ((st = dmalloc(&d8, 64)) != SCILMM_OK) return st;
+    D->allocs.push_back(d8);
+    HIPCHK(hipMemset(d8, 0, 64));
+    for (int c = 0; c < 3; ++c) {
+      Dev::CellSet& CS = D->cellset[c];
+      CS.dst = CS.grp = CS.srct = CS.srcq = (int64_t*)d8;
+      CS.md = CS.wd = (int32_t*)d8;
+    }
+    return SCILMM_OK;
+  }
+  CellCombo* d_cc = nullptr; int64_t* d_off = nullptr;
+  unsigned long long *key = nullptr, *skey = nullptr, *d_ninv = nullptr;
+  uint32_t *idx = nullptr, *sidx = nullptr;
+  int64_t *cst = nullptr, *csq = nullptr; int32_t *cmd = nullptr, *cwd = nullptr;
+  if ((st = tmalloc((void**)&d_cc, sizeof(CellCombo) * (size_t)ncc)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&d_off, sizeof(int64_t) * (size_t)(ncc + 1))) != SCILMM_OK) return st;
+  HIPCHK(hipMemcpy(d_cc, cc.data(), sizeof(CellCombo) * (size_t)ncc, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_off, off.data(), sizeof(int64_t) * (size_t)(ncc + 1), hipMemcpyHostToDevice));
+  if ((st = tmalloc((void**)&key, 8 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&skey, 8 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&idx, 4 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&sidx, 4 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&cst, 8 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&csq, 8 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&cmd, 4 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&cwd, 4 * (size_t)total)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&d_ninv, 8)) != SCILMM_OK) return st;
+  HIPCHK(hipMemset(d_ninv, 0, 8));
+  hipStream_t s0 = D->stream;
+  hipLaunchKernelGGL(k_emit_cells, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), dim3(256), 0, s0, total, ncc,
+                     (const CellCombo*)d_cc, (const int64_t*)d_off, D->v.sn_rows, key, idx, cst, csq, cmd, cwd, d_ninv);
+  void* cubtmp = nullptr;
+  size_t cubbytes = 0, need = 0;
+  auto ensure_tmp = [&](size_t bytes) -> int {
+    if (bytes <= cubbytes) return SCILMM_OK;
+    if ((st = tmalloc(&cubtmp, bytes)) != SCILMM_OK) return st;  // the smaller one is freed at exit as well
+    cubbytes = bytes;
+    return SCILMM_OK;
+  };
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key, skey, idx, sidx, total, 0, 62, s0));
+  if ((st = ensure_tmp(need)) != SCILMM_OK) return st;
+  need = cubbytes;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(cubtmp, need, key, skey, idx, sidx, total, 0, 62, s0));
+  unsigned long long ninv = 0;
+  HIPCHK(hipMemcpyAsync(&ninv, d_ninv, 8, hipMemcpyDeviceToHost, s0));
+  HIPCHK(hipStreamSynchronize(s0));
+  const int64_t nvalid = total - (int64_t)ninv;
+  D->n_cells = nvalid;
+  // groups of equal key (= equal class, level, target address)
+  unsigned long long* ukey = nullptr; int64_t* ucnt = nullptr; int64_t* ustart = nullptr; int64_t* d_ng = nullptr;
+  if ((st = tmalloc((void**)&ukey, 8 * (size_t)std::max<int64_t>(nvalid, 1))) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&ucnt, 8 * (size_t)std::max<int64_t>(nvalid, 1))) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&d_ng, 8)) != SCILMM_OK) return st;
+  HIPCHK(hipMemset(d_ng, 0, 8));
+  int64_t ng = 0;
+  if (nvalid > 0) {
+    need = 0;
+    HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, need, skey, ukey, ucnt, d_ng, (int)nvalid, s0));
+    if ((st = ensure_tmp(need)) != SCILMM_OK) return st;
+    need = cubbytes;
+    HIPCHK(hipcub::DeviceRunLengthEncode::Encode(cubtmp, need, skey, ukey, ucnt, d_ng, (int)nvalid, s0));
+    HIPCHK(hipMemcpyAsync(&ng, d_ng, 8, hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipStreamSynchronize(s0));
+  }
+  *ngroups_total = ng;
+  // final arrays (kept): group targets, entry offsets, entries
+  int64_t *udst = nullptr, *grp2 = nullptr, *ost = nullptr, *osq = nullptr; int32_t *omd = nullptr, *owd = nullptr;
+  if ((st = dmalloc((void**)&udst, 8 * (size_t)std::max<int64_t>(ng, 1))) != SCILMM_OK) return st; D->allocs.push_back(udst);
+  if ((st = dmalloc((void**)&grp2, 8 * (size_t)(ng + 1))) != SCILMM_OK) return st; D->allocs.push_back(grp2);
+  if ((st = dmalloc((void**)&ost, 8 * (size_t)std::max<int64_t>(nvalid, 1))) != SCILMM_OK) return st; D->allocs.push_back(ost);
+  if ((st = dmalloc((void**)&osq, 8 * (size_t)std::max<int64_t>(nvalid, 1))) != SCILMM_OK) return st; D->allocs.push_back(osq);
+  if ((st = dmalloc((void**)&omd, 4 * (size_t)std::max<int64_t>(nvalid, 1))) != SCILMM_OK) return st; D->allocs.push_back(omd);
+  if ((st = dmalloc((void**)&owd, 4 * (size_t)std::max<int64_t>(nvalid, 1))) != SCILMM_OK) return st; D->allocs.push_back(owd);
+  std::vector<unsigned int> counters((size_t)3 * NL * 2, 0u);
+  if (ng > 0) {
+    if ((st = tmalloc((void**)&ustart, 8 * (size_t)ng)) != SCILMM_OK) return st;
+    need = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, ucnt, ustart, (int)ng, s0));
+    if ((st = ensure_tmp(need)) != SCILMM_OK) return st;
+    need = cubbytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp, need, ucnt, ustart, (int)ng, s0));
+    unsigned long long *gkey = nullptr, *gkey_s = nullptr; uint32_t *gidx = nullptr, *order = nullptr; int64_t* cnt2 = nullptr;
+    unsigned int* d_counters = nullptr;
+    if ((st = tmalloc((void**)&gkey, 8 * (size_t)ng)) != SCILMM_OK) return st;
+    if ((st = tmalloc((void**)&gkey_s, 8 * (size_t)ng)) != SCILMM_OK) return st;
+    if ((st = tmalloc((void**)&gidx, 4 * (size_t)ng)) != SCILMM_OK) return st;
+    if ((st = tmalloc((void**)&order, 4 * (size_t)ng)) != SCILMM_OK) return st;
+    if ((st = tmalloc((void**)&cnt2, 8 * (size_t)ng)) != SCILMM_OK) return st;
+    if ((st = tmalloc((void**)&d_counters, 4 * counters.size())) != SCILMM_OK) return st;
+    HIPCHK(hipMemsetAsync(d_counters, 0, 4 * counters.size(), s0));
+    const unsigned gb = (unsigned)((ng + 255) / 256);
+    hipLaunchKernelGGL(k_group_keys, dim3(gb), dim3(256), 0, s0, ng, (const unsigned long long*)ukey, (const int64_t*)ucnt,
+                       (int64_t)16, gkey, gidx);
+    need = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, gkey, gkey_s, gidx, order, ng, 0, 62, s0));
+    if ((st = ensure_tmp(need)) != SCILMM_OK) return st;
+    need = cubbytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(cubtmp, need, gkey, gkey_s, gidx, order, ng, 0, 62, s0));
+    hipLaunchKernelGGL(k_gather_counts, dim3(gb), dim3(256), 0, s0, ng, (const uint32_t*)order, (const int64_t*)ucnt, cnt2);
+    need = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, cnt2, grp2, (int)ng, s0));
+    if ((st = ensure_tmp(need)) != SCILMM_OK) return st;
+    need = cubbytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp, need, cnt2, grp2, (int)ng, s0));
+    HIPCHK(hipMemcpy(grp2 + ng, &nvalid, 8, hipMemcpyHostToDevice));  // one element past what the scan writes
+    hipLaunchKernelGGL(k_finish_groups, dim3(gb), dim3(256), 0, s0, ng, NL, (const uint32_t*)order,
+                       (const unsigned long long*)gkey_s, udst, d_counters);
+    hipLaunchKernelGGL(k_gather_entries, dim3((unsigned)std::min<int64_t>((nvalid + 255) / 256, 1 << 20)), dim3(256), 0, s0, nvalid, ng,
+                       (const int64_t*)grp2, (const uint32_t*)order, (const int64_t*)ustart, (const uint32_t*)sidx,
+                       (const int64_t*)cst, (const int64_t*)csq, (const int32_t*)cmd, (const int32_t*)cwd, ost, osq, omd, owd);
+    HIPCHK(hipMemcpyAsync(counters.data(), d_counters, 4 * counters.size(), hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipStreamSynchronize(s0));
+  } else {
+    const int64_t zero = 0;
+    HIPCHK(hipMemcpy(grp2, &zero, 8, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipGetLastError());
+  int64_t gbase = 0, ebase_unused = 0;
+  (void)ebase_unused;
+  for (int c = 0; c < 3; ++c) {
+    Dev::CellSet& CS = D->cellset[c];
+    CS.dst = udst + gbase;
+    CS.grp = grp2 + gbase;
+    CS.srct = ost;
+    CS.srcq = osq;
+    CS.md = omd;
+    CS.wd = owd;
+    int64_t run = 0;
+    for (int32_t l = 0; l < NL; ++l) {
+      const int64_t ns = counters[((size_t)c * NL + l) * 2], nl = counters[((size_t)c * NL + l) * 2 + 1];
+      if (l < S.nlevels) {
+        CS.level_short[l] = ns;
+        run += ns + nl;
+        CS.level_ptr[l + 1] = run;
+      }
+    }
+    if (c == 0) *n_early = run;  // groups of the early class (diagnostic)
+    gbase += run;
+  }
+  return SCILMM_OK;
 }
 
 int ensure_device(scilmm_symbolic* sym, Dev** out) {
@@ -354,8 +529,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       std::vector<ComboDesc> cd, ccd;
       std::vector<int64_t> dend, dmidv, cend;  // per tile: end of its dense list, its early|late split, 4 compact ends
       std::vector<Cell> cells;
+      std::vector<CellCombo> cellcombos;  // device-built cell plan: the small combos themselves
       int64_t n_sparse = 0, n_compact = 0;
     };
+    // The cell lists are built on the device from the small combos (cellplan.hip.h); SCILMM_HOST_CELLS=1 keeps the
+    // host enumeration (same lists up to the order of the contributions inside a group).
+    const char* ehc = getenv("SCILMM_HOST_CELLS");
+    const bool gpu_cells = !(ehc && ehc[0] == '1') && S.nnzL_stored < ((int64_t)1 << 38);
+    std::vector<CellCombo> cellcombos;
     auto process_range = [&](int64_t gbeg, int64_t gend, Part& Pt) {
     std::vector<ComboDesc>& cd = Pt.cd;
     std::vector<ComboDesc>& ccd = Pt.ccd;
@@ -431,6 +612,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           continue;
         }
         Pt.n_sparse++;
+        if (gpu_cells) {
+          const bool clate = !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr];
+          Pt.cellcombos.push_back(CellCombo{x.loff, x.rowoff, S.sn_loff[sfr], S.sn_rowptr[sfr] + R0, x.md, x.wd, x.ta, x.nt, x.p0, x.nq,
+                                            x.ip0, (int32_t)ms, (int32_t)R0, (int32_t)(tile_end - R0), c0s, S.sn_level[sfr],
+                                            clate ? ((D->split_lv[S.sn_level[sfr]] && ti > 0) ? 2 : 1) : 0});
+          continue;
+        }
         const int32_t* rd = S.sn_rows.data() + x.rowoff;
         const int32_t* lo = rs + R0;
         for (int32_t t = x.ta; t < x.ta + x.nt; ++t) {
@@ -485,6 +673,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         cd.insert(cd.end(), Pt.cd.begin(), Pt.cd.end());
         ccd.insert(ccd.end(), Pt.ccd.begin(), Pt.ccd.end());
         cells.insert(cells.end(), Pt.cells.begin(), Pt.cells.end());
+        cellcombos.insert(cellcombos.end(), Pt.cellcombos.begin(), Pt.cellcombos.end());
+        std::vector<CellCombo>().swap(Pt.cellcombos);
         D->n_sparse_combos += Pt.n_sparse;
         D->n_compact_combos += Pt.n_compact;
         Part().cd.swap(Pt.cd);
@@ -497,7 +687,18 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     plap("classify combos, list cells");
     size_t split = 0;
     int64_t ngroups_total = 0;
-    {
+    if (gpu_cells) {
+      int64_t potential = 0;
+      for (const CellCombo& q : cellcombos) potential += (int64_t)q.nt * q.nq;
+      if (potential >= ((int64_t)1 << 31)) {
+        sym->err = "cell plan: more than 2^31 cells (raise SCILMM_CELL_LIMIT granularity or set SCILMM_HOST_CELLS=1)";
+        return SCILMM_ERR_ARG;
+      }
+      int64_t n_early_groups = 0;
+      if ((st = build_cells_device(sym, D, cellcombos, std::max(S.nlevels, 1), &ngroups_total, &n_early_groups)) != SCILMM_OK) return st;
+      split = (size_t)n_early_groups;
+      std::vector<CellCombo>().swap(cellcombos);
+    } else {
       // Cells are ordered by (late class, level, dst, st, sq): counting sort on (class, level), then every bucket is
       // sorted, cut into groups of equal target address (short groups first) and written to the upload arrays
       // independently on a few host threads (one global std::sort of 27 M cells cost 7 s of every first evaluation).
