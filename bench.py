@@ -29,7 +29,7 @@ WORKLOADS = {
     "10k": (10000, 0.001),
     "100k": (100000, 0.005),
     "300k": (300000, 0.003),     # scaling probe between configs[1] and configs[2] (2.0e9 nnz(L), 7.6e13 flops)
-    "1m": (1000000, 0.001),
+    "1m": (1000000, 0.001),      # configs[2]: n_eff 828k, nnz(L) 1.5e10 (123 GB), 1.6e15 flops -- see DESIGN.md
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; MI355X_MICROARCH.md lists no fp64 figure
 HBM_PEAK_GBS = 8000.0

@@ -446,10 +446,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   UP(upd_p1, upd_p1)
   UP(tile_front, tile_front)
   UP(tile_base, tile_base)
-  UP(combo_ptr, combo_ptr)
-  UP(combo_pair, combo_pair)
-  UP(combo_ta, combo_ta)
-  UP(combo_tb, combo_tb)
+  // (the per-tile combo arrays stay on the host: the kernels read the flattened descriptors of the plan below)
+  D->v.combo_ptr = nullptr;
+  D->v.combo_pair = nullptr;
+  D->v.combo_ta = nullptr;
+  D->v.combo_tb = nullptr;
   UP(asm_dst, asm_dst)
   UP(diag_dst, diag_dst)
   UP(pat_colptr, pat_colptr)
