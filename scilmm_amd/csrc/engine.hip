@@ -473,7 +473,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const int64_t nc = (int64_t)S.combo_pair.size();
     const int64_t ntiles0 = (int64_t)S.tile_front.size();
     const char* ecs = getenv("SCILMM_CELL_LIMIT");
-    const double cell_limit = ecs ? atof(ecs) : 2048.0;  // pairs with cells*width below this take the cell-wise path
+    const double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
     std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
     std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
     const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
