@@ -473,7 +473,26 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const int64_t nc = (int64_t)S.combo_pair.size();
     const int64_t ntiles0 = (int64_t)S.tile_front.size();
     const char* ecs = getenv("SCILMM_CELL_LIMIT");
-    const double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
+    double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
+    if (!ecs) {
+      // very large patterns: keep the expanded cell plan below ~1.5e9 cells (32-bit counts in the device sort;
+      // 32 B per cell) by lowering the limit -- the 1 M-individual config ends at 64
+      const double cand[5] = {4096.0, 1024.0, 256.0, 64.0, 16.0};
+      double cells_at[5] = {0, 0, 0, 0, 0};
+      for (int64_t c = 0; c < nc; ++c) {
+        const int32_t e = S.combo_pair[c];
+        const int32_t d = S.upd_src[e];
+        const double cellsn = (double)(S.combo_tb[c] - S.combo_ta[c]) * (double)(S.upd_p1[e] - S.upd_p0[e]);
+        const double vol = cellsn * (double)(S.sn_start[d + 1] - S.sn_start[d]);
+        for (int k = 0; k < 5; ++k)
+          if (vol <= cand[k]) cells_at[k] += cellsn;
+      }
+      int pick = 0;
+      while (pick < 4 && cells_at[pick] > 1.5e9) ++pick;
+      cell_limit = cand[pick];
+      if (getenv("SCILMM_VERBOSE") && pick > 0)
+        fprintf(stderr, "[scilmm plan] cell limit lowered to %.0f (%.3e cells)\n", cell_limit, cells_at[pick]);
+    }
     std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
     std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
     const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
@@ -864,8 +883,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost_d(c);
       }
       const int64_t big = (int64_t)1 << 60;
-      const int64_t per_e = allow_split ? std::min(max_item, std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items)) : big;
-      const int64_t per_l = allow_split ? std::min(max_item, std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items)) : big;
+      // (at most ~8192 items per launch: the slabs of a level must stay a few GB on the largest patterns)
+      const int64_t cap_e = std::max<int64_t>(max_item, total_e / 8192), cap_l = std::max<int64_t>(max_item, total_l / 8192);
+      const int64_t per_e = allow_split ? std::min(cap_e, std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items)) : big;
+      const int64_t per_l = allow_split ? std::min(cap_l, std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items)) : big;
       int64_t slots = 0;
       // a split level lists its diagonal tile first: the late items / reduce entries of that tile lead the level
       std::vector<int32_t> order(S.level_tiles.begin() + S.level_tile_ptr[l], S.level_tiles.begin() + S.level_tile_ptr[l + 1]);
