@@ -313,8 +313,9 @@ int build_cells_device(scilmm_symbolic* sym, Dev* D, const std::vector<CellCombo
     need = cubbytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(cubtmp, need, cnt2, grp2, (int)ng, s0));
     HIPCHK(hipMemcpy(grp2 + ng, &nvalid, 8, hipMemcpyHostToDevice));  // one element past what the scan writes
-    hipLaunchKernelGGL(k_finish_groups, dim3(gb), dim3(256), 0, s0, ng, NL, (const uint32_t*)order,
-                       (const unsigned long long*)gkey_s, udst, d_counters);
+    hipLaunchKernelGGL(k_finish_groups, dim3(gb), dim3(256), 0, s0, ng, (const unsigned long long*)gkey_s, udst);
+    hipLaunchKernelGGL(k_bucket_counts, dim3((unsigned)((counters.size() + 255) / 256)), dim3(256), 0, s0, (int32_t)counters.size(), NL,
+                       ng, (const unsigned long long*)gkey_s, d_counters);
     hipLaunchKernelGGL(k_gather_entries, dim3((unsigned)std::min<int64_t>((nvalid + 255) / 256, 1 << 20)), dim3(256), 0, s0, nvalid, ng,
                        (const int64_t*)grp2, (const uint32_t*)order, (const int64_t*)ustart, (const uint32_t*)sidx,
                        (const int64_t*)cst, (const int64_t*)csq, (const int32_t*)cmd, (const int32_t*)cwd, ost, osq, omd, owd);
