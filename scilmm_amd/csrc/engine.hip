@@ -665,7 +665,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     }
     };
     {
-      const unsigned nth = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), ntiles0));
+      const unsigned nth = (unsigned)std::max<int64_t>(
+          1, std::min<int64_t>(std::min(nc > 50000000 ? 48u : 16u, std::max(1u, std::thread::hardware_concurrency())), ntiles0));
       std::vector<int64_t> cut(nth + 1, ntiles0);
       cut[0] = 0;
       for (unsigned k = 1; k < nth; ++k) {
