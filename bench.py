@@ -180,7 +180,7 @@ def main():
     if rank == 0:
         K = args.steps
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_v6_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r1_v10_traffic.json")
         if args.workload == "100k" and os.path.exists(tpath):
             traffic = json.load(open(tpath))["bytes_per_launch"]  # PMC pass taken offline (see the file), per launch
         upd_s = prof["update_ms"] / 1e3
