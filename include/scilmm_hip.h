@@ -70,6 +70,15 @@ int scilmm_symbolic_get(const scilmm_symbolic* sym, const char* what, void* out,
 const char* scilmm_symbolic_error(const scilmm_symbolic* sym);
 void scilmm_symbolic_free(scilmm_symbolic* sym);
 
+/* The ordering step of cholmod_analyze alone (SparseCholesky.py:17 ordering_method): fill-reducing permutation of a
+ * symmetric CSR pattern (only entries with column < row are read).  method 0 = approximate minimum degree,
+ * 1 = nested dissection (graph bisection, minimum degree on the leaves).  perm_out[new] = old. */
+int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32_t method, int32_t* perm_out);
+/* nnz(L), sum colcount^2 and the largest column count of the factor of pattern[perm][:,perm] (perm NULL = natural):
+ * elimination tree + column counts only -- what the ordering study in profiles/ and bench.py's fill figures use. */
+int scilmm_fill_count(int32_t n, const int64_t* indptr, const int32_t* indices, const int32_t* perm, int64_t* nnzL,
+                      double* flops, int32_t* max_colcount);
+
 /* --- values: one upload per A_k replaces the per-evaluation CSR arithmetic of matrices_weighted_sum
  * (SparseCholesky.py:55-59).  data_k is the CSR data array matching indptr[k]/indices[k]. */
 int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k);

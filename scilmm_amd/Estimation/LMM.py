@@ -65,6 +65,9 @@ def LMM(cholesky, mats, covariates, y, with_intercept=True, reml=True, sim_num=1
     _, L_CT_invV_C, _, fixed_effects = compute_fixed_effects(factor, y, covariates)
     p_values = compute_fixed_effects_p_value(y, covariates, fixed_effects, L_CT_invV_C)
     sigmas_sigmas = compute_sig_of_sig(mats, covariates, factor, y, sim_num)
+    del factor
+    if isinstance(cholesky, SparseCholesky):
+        cholesky.release_factors()
     return {"covariance coefficients": mats_coefficients,
             "covariates coefficients": fixed_effects,
             "covariance std": sigmas_sigmas,

@@ -59,16 +59,20 @@ class SparseCholesky(object):
         self._cache = {}
 
     def _ordering(self):
-        return 'natural' if self._ordering_method == 'natural' else 'amd'
+        # 'nesdis' (the reference's choice, SparseCholesky.py:17) = the engine's nested dissection; 'default' and
+        # 'amd' = its approximate minimum degree; 'best' = whichever of the two gives fewer factor flops
+        return {'natural': 'natural', 'nesdis': 'nesdis', 'best': 'best'}.get(self._ordering_method, 'amd')
 
     @staticmethod
     def _quick_id(mats):
-        """Cheap identity of a list of matrices: object ids, sizes and a few boundary values (no full pass)."""
+        """Identity of a list of CSR matrices that an in-place edit cannot slip past: object ids and buffer
+        addresses (the cache keeps strong references, so ids are not recycled) plus a FULL-pass checksum of the
+        values (sum and sum of squares: two streaming reductions, ~1 s per 1e9 entries)."""
         out = []
         for m in mats:
             d = m.data
-            out.append((id(m), m.shape, m.nnz, d.ctypes.data if d.size else 0,
-                        d[:4].tobytes() + d[-4:].tobytes() if d.size else b""))
+            out.append((id(m), m.shape, m.nnz, d.ctypes.data if d.size else 0, m.indices.ctypes.data if d.size else 0,
+                        m.indptr.ctypes.data, float(d.sum()) if d.size else 0.0, float(np.dot(d, d)) if d.size else 0.0))
         return tuple(out)
 
     def engine_for(self, mats):
@@ -79,9 +83,10 @@ class SparseCholesky(object):
                 return self._last_sym  # same objects as in the previous evaluation: nothing to re-hash
         else:
             qid = None
-        mats = [sparse.csr_matrix(m) for m in mats]
-        for m in mats:
-            m.sort_indices()
+        held = list(mats)  # strong references: the ids inside qid stay valid while it is cached
+        # (a matrix with unsorted indices is copied before sorting: the caller's arrays are never touched)
+        mats = [m if (sparse.isspmatrix_csr(m) and m.has_sorted_indices) else sparse.csr_matrix(m).sorted_indices()
+                for m in mats]
         key = _pattern_key(mats)
         hit = self._cache.get(key)
         if hit is None:
@@ -93,8 +98,12 @@ class SparseCholesky(object):
                 if not np.array_equal(datas[k], m.data):
                     sym.set_values(k, m.data)
                     datas[k] = m.data.copy()
-        self._last_qid, self._last_sym = qid, sym
+        self._last_qid, self._last_sym, self._last_held = qid, sym, held
         return sym
+
+    def release_factors(self):
+        """Free the numeric factor(s) kept between evaluations (the symbolic analysis and the A_k values stay)."""
+        self.__dict__.get('_factor_state', {}).clear()
 
     def __call__(self, sparse_mat):
         sym = self.engine_for([sparse_mat])
@@ -257,8 +266,17 @@ def estimate_var_comps(cholesky_func, mats, covariates, y, reml=True, sim_num=10
 
 
 def _final_factor(cholesky_func, mats, coefficients):
+    """The reference factorizes once more at the optimum (SparseCholesky.py:182).  On the device the evaluation
+    factor is re-used (refactorize): a second resident factor would double the largest allocation (123 GB at 1M)."""
     if _is_hip(cholesky_func):
-        return cholesky_func.engine_for(mats).factorize(coefficients)
+        sym = cholesky_func.engine_for(mats)
+        fac = cholesky_func.__dict__.setdefault('_factor_state', {}).get(id(sym))
+        if fac is not None:
+            return fac.refactorize(coefficients)
+        fac = sym.factorize(coefficients)
+        cholesky_func._factor_state.clear()
+        cholesky_func._factor_state[id(sym)] = fac
+        return fac
     return cholesky_func(matrices_weighted_sum(mats, coefficients))
 
 
@@ -295,6 +313,9 @@ def REML(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=Fal
     factor = _final_factor(cholesky_func, mats, varcomp_estimates)
     _, _, _, fixed_effects = estimate_fixed_effects(factor, y, covariates)
     sigmas_sigmas = compute_varcomp_stderr(mats, covariates, factor, y, sim_num)
+    del factor
+    if _is_hip(cholesky_func):
+        cholesky_func.release_factors()
     return {"covariance coefficients": varcomp_estimates,
             "covariates coefficients": fixed_effects,
             "covariance std": sigmas_sigmas}

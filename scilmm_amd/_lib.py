@@ -62,6 +62,7 @@ SYMBOLS = [
     "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
+    "scilmm_order", "scilmm_fill_count",
 ]
 
 _lib = None
@@ -110,6 +111,8 @@ def lib():
     L.scilmm_ibd_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.scilmm_ibd_free.argtypes = [vp]
     L.scilmm_ibd_free.restype = None
+    L.scilmm_order.argtypes = [i32, vp, vp, i32, vp]
+    L.scilmm_fill_count.argtypes = [i32, vp, vp, vp, P(i64), P(dbl), P(i32)]
     _lib = L
     return L
 
@@ -143,3 +146,26 @@ def symbolic_get(sym, name):
     out = np.empty(n.value, dtype=_GET_DTYPES.get(name, np.int32))
     check(lib().scilmm_symbolic_get(sym, name.encode(), ptr(out), C.byref(n)), sym)
     return out
+
+
+ORDER_METHODS = {"amd": 0, "nesdis": 1}
+
+
+def order(A, method="amd"):
+    """Fill-reducing permutation (perm[new] = old) of the symmetric pattern of scipy CSR matrix A."""
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    perm = np.empty(A.shape[0], dtype=np.int32)
+    check(lib().scilmm_order(A.shape[0], ptr(indptr), ptr(indices), ORDER_METHODS[method], ptr(perm)))
+    return perm
+
+
+def fill_count(A, perm=None):
+    """(nnz(L), sum colcount^2, max colcount) of the factor of A[perm][:, perm]'s pattern."""
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    nz, fl, mx = C.c_int64(0), C.c_double(0), C.c_int32(0)
+    p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+    check(lib().scilmm_fill_count(A.shape[0], ptr(indptr), ptr(indices), None if p is None else ptr(p), C.byref(nz),
+                                  C.byref(fl), C.byref(mx)))
+    return nz.value, fl.value, mx.value

@@ -1,6 +1,7 @@
 // C-ABI entry points for the host-side symbolic phase (no GPU needed). Declared in include/scilmm_hip.h.
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/scilmm_hip.h"
 #include "handles.h"
@@ -100,6 +101,43 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
   GET("child_ptr", child_ptr)
   GET("child_idx", child_idx)
   return SCILMM_ERR_ARG;
+}
+
+int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32_t method, int32_t* perm_out) {
+  if (n < 0 || !indptr || !indices || !perm_out) return SCILMM_ERR_ARG;
+  // symmetrised adjacency without the diagonal
+  std::vector<int64_t> gptr((size_t)n + 1, 0);
+  for (int32_t i = 0; i < n; ++i)
+    for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+      const int32_t j = indices[e];
+      if (j < 0 || j >= n || j >= i) continue;
+      gptr[i + 1]++;
+      gptr[j + 1]++;
+    }
+  for (int32_t i = 0; i < n; ++i) gptr[i + 1] += gptr[i];
+  std::vector<int32_t> gidx((size_t)gptr[n]);
+  {
+    std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (j < 0 || j >= n || j >= i) continue;
+        gidx[fill[i]++] = j;
+        gidx[fill[j]++] = i;
+      }
+  }
+  if (method == 0) {
+    scilmm::amd_order(n, gptr.data(), gidx.data(), perm_out, 10.0);
+    return SCILMM_OK;
+  }
+  return SCILMM_ERR_ARG;
+}
+
+int scilmm_fill_count(int32_t n, const int64_t* indptr, const int32_t* indices, const int32_t* perm, int64_t* nnzL,
+                      double* flops, int32_t* max_colcount) {
+  if (n < 0 || !indptr || !indices) return SCILMM_ERR_ARG;
+  scilmm::fill_count(n, indptr, indices, perm, nnzL, flops, max_colcount, nullptr);
+  return SCILMM_OK;
 }
 
 const char* scilmm_symbolic_error(const scilmm_symbolic* h) { return h ? h->err.c_str() : "null handle"; }

@@ -26,6 +26,7 @@ using namespace scilmm;
 namespace {
 
 struct Dev {
+  int device = 0;                  // HIP device the handle was created on; every entry point runs on it (DevGuard)
   hipStream_t stream = nullptr;
   DevSym v{};
   std::vector<void*> allocs;
@@ -121,10 +122,20 @@ struct Dev {
   int64_t n_fold = 0;
   double* d_push_partial = nullptr;  // [slots][NB][RPMAX]
   int32_t* d_chain_flags = nullptr;  // [chain_T * RPMAX/CW] epoch stamps
-  int32_t* d_chain_err = nullptr;
+  int32_t* d_chain_err = nullptr;    // [0] error flag, [1] progress beacon, [2] ticket counter of the running sweep
+  int32_t* h_chain_err = nullptr;    // pinned mirror of [0], refreshed by a queued copy after every solve
   int32_t chain_epoch = 0;
   std::vector<hipEvent_t> pev;     // 4 events per level when profiling
 };
+
+// Schedule / tuning switches (SCILMM_LOOK_DEPTH, SCILMM_CELL_LIMIT, ...) are honoured only when SCILMM_TUNING=1 is set
+// as well, so that a stray variable in a production environment cannot change the schedule.  Every value of every
+// such switch gives the same factor to rounding (parity-tested); switches that would change RESULTS (the timing
+// ablations) exist only in builds with -DSCILMM_DIAG.  SCILMM_VERBOSE / SCILMM_LEVEL_DUMP only print.
+inline const char* tune_env(const char* name) {
+  static const bool on = [] { const char* t = tune_env("SCILMM_TUNING"); return t && t[0] == '1'; }();
+  return on ? getenv(name) : nullptr;
+}
 
 #define HIPCHK(call)                                                                                   \
   do {                                                                                                 \
@@ -134,6 +145,21 @@ struct Dev {
       return SCILMM_ERR_DEVICE;                                                                        \
     }                                                                                                  \
   } while (0)
+
+// Makes the handle's device current for the duration of an entry point and restores the caller's device afterwards
+// (a handle may be used from a thread whose current device is a different one).
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(const scilmm_symbolic* sym) {
+    const Dev* D = sym ? (const Dev*)sym->device : nullptr;
+    if (!D) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != D->device) switched = hipSetDevice(D->device) == hipSuccess;
+  }
+  ~DevGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
 
 template <typename T>
 int upload(scilmm_symbolic* sym, Dev* D, const std::vector<T>& h, const T** out) {
@@ -170,6 +196,7 @@ void dev_free(void* p) {
   for (auto& cs : D->cside)
     if (cs) (void)hipStreamDestroy(cs);
   if (D->rest) (void)hipStreamDestroy(D->rest);
+  if (D->h_chain_err) (void)hipHostFree(D->h_chain_err);
   for (auto& e : D->chain_ev)
     if (e) (void)hipEventDestroy(e);
   if (D->stream) (void)hipStreamDestroy(D->stream);
@@ -364,6 +391,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   Dev* D = new Dev();
   sym->device = D;
   sym->device_free = dev_free;
+  if (hipGetDevice(&D->device) != hipSuccess) D->device = 0;  // the handle binds to the caller's current device
   const bool pverb = getenv("SCILMM_VERBOSE") != nullptr;
   auto ptl = std::chrono::steady_clock::now();
   auto plap = [&](const char* what) {
@@ -381,10 +409,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     HIPCHK(hipStreamCreateWithPriority(&D->stream, hipStreamNonBlocking, hi));
     // SCILMM_RESERVE_CUS = r > 0: the look-ahead side streams are created with a CU mask that leaves r CUs per
     // XCD-group free, so the main stream's single-workgroup kernels never queue behind resident update items.
-    const char* er = getenv("SCILMM_RESERVE_CUS");
+    const char* er = tune_env("SCILMM_RESERVE_CUS");
     const int reserve = er ? atoi(er) : 0;
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    HIPCHK(hipGetDeviceProperties(&prop, D->device));
     const int ncu = prop.multiProcessorCount;
     if (reserve > 0 && reserve < ncu) {
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
@@ -403,7 +431,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
       HIPCHK(hipStreamCreateWithPriority(&D->cside[0], hipStreamNonBlocking, lo));
       HIPCHK(hipStreamCreateWithPriority(&D->cside[1], hipStreamNonBlocking, lo));
-      const char* ens3 = getenv("SCILMM_SIDE_STREAMS");
+      const char* ens3 = tune_env("SCILMM_SIDE_STREAMS");
       if (ens3 && atoi(ens3) == 3) {
         HIPCHK(hipStreamCreateWithPriority(&D->side3, hipStreamNonBlocking, lo));
         D->nside = 3;
@@ -426,11 +454,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       sym->err = "symbolic analysis has supernode blocks wider than the kernels' block width (max_width > NB)";
       return SCILMM_ERR_ARG;
     }
-  const char* nm = getenv("SCILMM_NO_MFMA");
+  const char* nm = tune_env("SCILMM_NO_MFMA");
   D->use_mfma = !(nm && nm[0] == '1');
-  const char* ab = getenv("SCILMM_ABLATE");
+#ifdef SCILMM_DIAG
+  const char* ab = getenv("SCILMM_ABLATE");  // timing ablations (WRONG numbers): diagnostic builds only
   D->ablate = ab ? atoi(ab) : 0;
-  const char* uv = getenv("SCILMM_UPDATE_VARIANT");
+#endif
+  const char* uv = tune_env("SCILMM_UPDATE_VARIANT");
   if (uv) D->update_variant = atoi(uv);
   D->v.n = S.n;
   D->v.nsuper = S.nsuper;
@@ -473,7 +503,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   {
     const int64_t nc = (int64_t)S.combo_pair.size();
     const int64_t ntiles0 = (int64_t)S.tile_front.size();
-    const char* ecs = getenv("SCILMM_CELL_LIMIT");
+    const char* ecs = tune_env("SCILMM_CELL_LIMIT");
     double cell_limit = ecs ? atof(ecs) : 4096.0;  // pairs with cells*width below this take the cell-wise path
     if (!ecs) {
       // very large patterns: keep the expanded cell plan below ~1.5e9 cells (32-bit counts in the device sort;
@@ -496,10 +526,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     }
     std::vector<ComboDesc> cd;                 // dense combos only, grouped by tile
     std::vector<int64_t> dptr((size_t)ntiles0 + 1, 0), dmid((size_t)ntiles0 + 1, 0);
-    const char* ela = getenv("SCILMM_NO_LOOKAHEAD");
+    const char* ela = tune_env("SCILMM_NO_LOOKAHEAD");
     const bool lookahead = !(ela && ela[0] == '1');
     {
-      const char* eld = getenv("SCILMM_LOOK_DEPTH");
+      const char* eld = tune_env("SCILMM_LOOK_DEPTH");
       D->look_depth = eld ? std::max(1, atoi(eld)) : 2;  // measured at 100k: depth 1 81.4 ms, 2 77.6 ms, 3 78.4 ms
     }
     const int32_t depth = D->look_depth;
@@ -509,8 +539,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       // Opt-in (SCILMM_SPLIT_CHAIN=1): measured at the 100k pedigree it moves factorize from 74.7 to 73.8 ms only --
       // the rest stream's [trsm of level l-1, late update of level l] is as long as the main stream's chain, and
       // under the saturating early updates both run ~1.6x slower than isolated.
-      const char* ens = getenv("SCILMM_SPLIT_CHAIN");
-      const char* ecp = getenv("SCILMM_COMPACT");
+      const char* ens = tune_env("SCILMM_SPLIT_CHAIN");
+      const char* ecp = tune_env("SCILMM_COMPACT");
       const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1');
       int64_t why[3] = {0, 0, 0};
       for (int32_t l = 1; allow && l + 1 < S.nlevels; ++l) {
@@ -536,11 +566,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // ~4 us in the padded dense kernel: mode 1 (two items per tile, after the dense kernel) gives factorize
     // 66 -> 96 ms, mode 2 (32-combo items with private slabs beside the dense kernel) 66 -> 91 ms.  It needs a
     // software-pipelined item (several combos in flight) to pay off.
-    const char* enoc = getenv("SCILMM_COMPACT");
+    const char* enoc = tune_env("SCILMM_COMPACT");
     const bool allow_compact = enoc && (enoc[0] == '1' || enoc[0] == '2');
     D->compact_mode = allow_compact ? (enoc[0] == '2' ? 2 : 1) : 0;
     const bool compact_slabs = D->compact_mode == 2;
-    const char* ecf = getenv("SCILMM_COMPACT_FACTOR");
+    const char* ecf = tune_env("SCILMM_COMPACT_FACTOR");
     const double compact_factor = ecf ? atof(ecf) : 2.0;
     struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };  // late: 0 early, 1 late (main), 2 late (rest stream)
     std::vector<Cell> cells;
@@ -555,7 +585,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     };
     // The cell lists are built on the device from the small combos (cellplan.hip.h); SCILMM_HOST_CELLS=1 keeps the
     // host enumeration (same lists up to the order of the contributions inside a group).
-    const char* ehc = getenv("SCILMM_HOST_CELLS");
+    const char* ehc = tune_env("SCILMM_HOST_CELLS");
     const bool gpu_cells = !(ehc && ehc[0] == '1') && S.nnzL_stored < ((int64_t)1 << 38);
     std::vector<CellCombo> cellcombos;
     auto process_range = [&](int64_t gbeg, int64_t gend, Part& Pt) {
@@ -842,7 +872,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->red_ptr.assign(S.nlevels + 1, 0);
     std::vector<int32_t> red_tiles;
     int64_t max_slots = 0;
-    const char* ens = getenv("SCILMM_NO_SPLITK");
+    const char* ens = tune_env("SCILMM_NO_SPLITK");
     const bool allow_split = !(ens && ens[0] == '1');
     // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Each launch (the early
     // and the late part of a level) is cut into about 4 work items per CU of equal cost, so that one launch
@@ -851,10 +881,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     auto combo_cost = [&](int64_t c) -> int64_t { return combo_cost_d(c); };
     // ... but an item never exceeds max_item units (~0.5 ms): the main stream's kernels start in the slots that
     // retiring update items free, so long items starve the per-level chain (300k probe: 2.3 ms per trsm launch)
-    const char* emi = getenv("SCILMM_MAX_ITEM");
-    const char* eti = getenv("SCILMM_TARGET_ITEMS");
-    const char* emn = getenv("SCILMM_MIN_ITEM");
-    const char* eci = getenv("SCILMM_COMPACT_ITEM");
+    const char* emi = tune_env("SCILMM_MAX_ITEM");
+    const char* eti = tune_env("SCILMM_TARGET_ITEMS");
+    const char* emn = tune_env("SCILMM_MIN_ITEM");
+    const char* eci = tune_env("SCILMM_COMPACT_ITEM");
     const int64_t compact_item = std::max<int64_t>(1, eci ? atoll(eci) : 32);  // combos per slab-mode compact item
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
@@ -1040,12 +1070,12 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // wide fronts just below it; every dependency of a member is either a member or finished by the level kernels)
     // (a level joins while it has at most `wide` fronts: a pull step costs ~8 us whatever its size, so the many
     // small fronts of the lower levels stay with the level kernels -- measured optimum at the 100k pedigree)
-    const char* ecap = getenv("SCILMM_CHAIN_CAP");
-    const char* ewide = getenv("SCILMM_CHAIN_WIDE");
+    const char* ecap = tune_env("SCILMM_CHAIN_CAP");
+    const char* ewide = tune_env("SCILMM_CHAIN_WIDE");
     const int32_t cap = ecap ? atoi(ecap) : 2048, wide = ewide ? atoi(ewide) : 12;
     int32_t l0 = S.nlevels;
     while (l0 > 0 && S.level_ptr[l0] - S.level_ptr[l0 - 1] <= wide && S.level_ptr[S.nlevels] - S.level_ptr[l0 - 1] <= cap) --l0;
-    const char* enc = getenv("SCILMM_NO_CHAIN");
+    const char* enc = tune_env("SCILMM_NO_CHAIN");
     int32_t T = l0 < S.nlevels ? S.level_ptr[S.nlevels] - S.level_ptr[l0] : 0;
     if (S.nlevels - l0 < 4 || (enc && enc[0] == '1')) T = 0;
     D->chain_T = T;
@@ -1112,7 +1142,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       {
         // one workgroup sweeps its rows 32 at a time (~3.5 us per step): a descendant with 10^4 rows in the chain
         // would take a millisecond alone, so long groups are cut into slices of <= slice_rows rows
-        const char* esr = getenv("SCILMM_PUSH_SLICE");
+        const char* esr = tune_env("SCILMM_PUSH_SLICE");
         const int64_t slice_rows = std::max<int64_t>(256, esr ? atoll(esr) : 512);
         std::vector<int64_t> gptr2;
         std::vector<int32_t> gp2;
@@ -1186,10 +1216,12 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if ((st = upload(sym, D, gpairs, &t32)) != SCILMM_OK) return st; D->d_cg_pairs = (int32_t*)t32;
       if ((st = upload(sym, D, gslot, &t32)) != SCILMM_OK) return st; D->d_cg_slot = (int32_t*)t32;
       if ((st = upload(sym, D, fold, &t32)) != SCILMM_OK) return st; D->d_fold = (int32_t*)t32;
-      std::vector<int32_t> zeros((size_t)T * (RPMAX / CW) + 1, 0);
+      std::vector<int32_t> zeros((size_t)T * (RPMAX / CW) + 4, 0);
       if ((st = upload(sym, D, zeros, &t32)) != SCILMM_OK) return st;
       D->d_chain_flags = (int32_t*)t32;
       D->d_chain_err = D->d_chain_flags + (size_t)T * (RPMAX / CW);
+      HIPCHK(hipHostMalloc((void**)&D->h_chain_err, sizeof(int32_t), hipHostMallocDefault));
+      *D->h_chain_err = 0;
       if (getenv("SCILMM_VERBOSE"))
         fprintf(stderr, "[scilmm plan] chain sweep: %d fronts (levels %d..%d), %lld inner pairs (%lld column maps), %lld outside pairs in %lld groups\n",
                 T, l0, S.nlevels - 1, (long long)fl.size(), (long long)(colmap.size() / NB), (long long)outside.size(), (long long)D->chain_groups);
@@ -1214,8 +1246,10 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+#ifdef SCILMM_DIAG
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+#endif
   HIPCHK(hipFuncSetAttribute((const void*)k_update<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
   return SCILMM_OK;
@@ -1321,11 +1355,19 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     for (size_t i = old; i < D->pev.size(); ++i) HIPCHK(hipEventCreate(&D->pev[i]));
   }
   auto launch_update = [&](hipStream_t stream, const UpdWork* work, int64_t cnt, double* scratch_half) {
-    if (D->use_mfma && D->ablate == 1)
+#ifdef SCILMM_DIAG
+    if (D->use_mfma && D->ablate == 1) {
       hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-    else if (D->use_mfma && D->ablate == 2)
+      launches++;
+      return;
+    }
+    if (D->use_mfma && D->ablate == 2) {
       hipLaunchKernelGGL((k_update<true, 2>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-    else if (D->use_mfma && D->update_variant == 2)
+      launches++;
+      return;
+    }
+#endif
+    if (D->use_mfma && D->update_variant == 2)
       hipLaunchKernelGGL((k_update2<true>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     else if (D->use_mfma)
       hipLaunchKernelGGL((k_update<true, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
@@ -1636,6 +1678,14 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
   }
   int stc = ensure_work(sym, D);
   if (stc != SCILMM_OK) return stc;
+  if (D->h_chain_err && *D->h_chain_err != 0) {
+    // an earlier (already completed) chain sweep timed out: report it before queueing more work on top of it
+    HIPCHK(hipStreamSynchronize(D->stream));
+    HIPCHK(hipMemset(D->d_chain_err, 0, sizeof(int32_t)));
+    *D->h_chain_err = 0;
+    sym->err = "chain sweep: a workgroup timed out waiting for its predecessor (previous solve)";
+    return SCILMM_ERR_DEVICE;
+  }
   hipStream_t st = D->stream;
   const int64_t ntiles_all = (int64_t)S.level_tiles.size();
   const bool mf = D->use_mfma;
@@ -1680,14 +1730,15 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
       if (D->chain_T > 0) {
         const unsigned grid = (unsigned)D->chain_T * gy;
         const int32_t ep = ++D->chain_epoch;
+        HIPCHK(hipMemsetAsync(D->d_chain_err + 2, 0, sizeof(int32_t), st));
         if (mf)
           hipLaunchKernelGGL((k_chain<true, false>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
                              (const int32_t*)D->d_cf_ptr, (const ChainPair*)D->d_cf, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
         else
           hipLaunchKernelGGL((k_chain<false, false>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
                              (const int32_t*)D->d_cf_ptr, (const ChainPair*)D->d_cf, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
       }
       if (!mid_recorded) {
         HIPCHK(hipEventRecord(D->ev[4], st));
@@ -1696,14 +1747,15 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
       if (D->chain_T > 0) {
         const unsigned grid = (unsigned)D->chain_T * gy;
         const int32_t ep = ++D->chain_epoch;
+        HIPCHK(hipMemsetAsync(D->d_chain_err + 2, 0, sizeof(int32_t), st));
         if (mf)
           hipLaunchKernelGGL((k_chain<true, true>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
                              (const int32_t*)D->d_cb_ptr, (const ChainPair*)D->d_cb, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
         else
           hipLaunchKernelGGL((k_chain<false, true>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
                              (const int32_t*)D->d_cb_ptr, (const ChainPair*)D->d_cb, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err);
+                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
         // descendants below the chain: all their chain targets are final now, one read-modify-write each
         if (D->chain_groups > 0) {
           if (mf)
@@ -1756,6 +1808,7 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     }
   }
   if (!mid_recorded) HIPCHK(hipEventRecord(D->ev[4], st));
+  if (D->h_chain_err && mode == 0) HIPCHK(hipMemcpyAsync(D->h_chain_err, D->d_chain_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(D->ev[5], st));
   HIPCHK(hipGetLastError());
   D->rhs_pending = mode;
@@ -1769,6 +1822,7 @@ int finish_rhs_timing(scilmm_symbolic* sym, Dev* D, int mode) {
     HIPCHK(hipMemcpy(&cerr, D->d_chain_err, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (cerr != 0) {
       HIPCHK(hipMemset(D->d_chain_err, 0, sizeof(int32_t)));
+      if (D->h_chain_err) *D->h_chain_err = 0;
       sym->err = "chain sweep: a workgroup timed out waiting for its predecessor";
       return SCILMM_ERR_DEVICE;
     }
@@ -1834,6 +1888,7 @@ extern "C" {
 
 int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) {
   if (!sym || !sym->S || !data_k) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   const Symbolic& S = *sym->S;
   if (k < 0 || k >= S.K) return SCILMM_ERR_ARG;
   Dev* D;
@@ -1855,6 +1910,7 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) 
 
 int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor** out, int32_t* bad_col) {
   if (!sym || !sym->S || !sigma2 || !out) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
@@ -1880,22 +1936,26 @@ int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor**
 
 int scilmm_refactorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
   if (!fac || !fac->sym || !sigma2) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   return run_factorize(fac, sigma2, bad_col);
 }
 
 int scilmm_refactorize_async(scilmm_factor* fac, const double* sigma2) {
   if (!fac || !fac->sym || !sigma2) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   return run_factorize(fac, sigma2, nullptr, false);
 }
 
 int scilmm_factor_wait(scilmm_factor* fac, int32_t* bad_col) {
   if (!fac || !fac->sym) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   if (!fac->pending) return fac->valid ? SCILMM_OK : SCILMM_ERR_STATE;
   return finish_factorize(fac, bad_col);
 }
 
 void scilmm_factor_free(scilmm_factor* fac) {
   if (!fac) return;
+  DevGuard guard(fac->sym);
   if (fac->pending) (void)finish_factorize(fac, nullptr);
   if (fac->h_status) (void)hipHostFree(fac->h_status);
   if (fac->L) (void)hipFree(fac->L);
@@ -1907,6 +1967,7 @@ void scilmm_factor_free(scilmm_factor* fac) {
 
 int scilmm_logdet(scilmm_factor* fac, double* out) {
   if (!fac || !fac->sym || !out) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   scilmm_symbolic* sym = fac->sym;
   if (fac->pending) {
     int stp = finish_factorize(fac, nullptr);
@@ -1927,6 +1988,7 @@ int scilmm_logdet(scilmm_factor* fac, double* out) {
 
 static int host_rhs(scilmm_factor* fac, const double* B, int32_t r, double* X, int mode) {
   if (!fac || !fac->sym || !B || !X || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   scilmm_symbolic* sym = fac->sym;
   Dev* D = (Dev*)sym->device;
   const Symbolic& S = *sym->S;
@@ -1948,15 +2010,18 @@ int scilmm_lmul(scilmm_factor* fac, const double* R, int32_t r, double* Z) { ret
 
 int scilmm_solve_dev(scilmm_factor* fac, const double* dB, int32_t r, double* dX) {
   if (!fac || !fac->sym || !dB || !dX || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   return run_rhs(fac, dB, r, dX, 0);
 }
 int scilmm_lmul_dev(scilmm_factor* fac, const double* dR, int32_t r, double* dZ) {
   if (!fac || !fac->sym || !dR || !dZ || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   return run_rhs(fac, dR, r, dZ, 1);
 }
 
 int scilmm_quadforms_dev(scilmm_symbolic* sym, int32_t k, const double* dU, int32_t r, double* d_out) {
   if (!sym || !sym->S || !dU || !d_out || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
@@ -1965,6 +2030,7 @@ int scilmm_quadforms_dev(scilmm_symbolic* sym, int32_t k, const double* dU, int3
 
 int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r, double* out) {
   if (!sym || !sym->S || !U || !out || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
@@ -1985,6 +2051,7 @@ int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r
 
 int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y) {
   if (!sym || !sym->S || !X || !Y || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
@@ -2019,6 +2086,7 @@ int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, dou
 
 int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double* vals, int64_t* nnz) {
   if (!fac || !fac->sym || !nnz) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
   scilmm_symbolic* sym = fac->sym;
   const Symbolic& S = *sym->S;
   int64_t total = 0;
@@ -2060,6 +2128,7 @@ int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double
 
 int scilmm_sync(scilmm_symbolic* sym) {
   if (!sym || !sym->device) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   Dev* D = (Dev*)sym->device;
   HIPCHK(hipStreamSynchronize(D->stream));
   if (D->rhs_pending >= 0) return finish_rhs_timing(sym, D, D->rhs_pending);
@@ -2074,6 +2143,7 @@ int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out) {
 
 int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on) {
   if (!sym || !sym->S) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;

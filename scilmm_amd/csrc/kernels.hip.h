@@ -1562,8 +1562,10 @@ __global__ __launch_bounds__(256) void k_push_fold(DevSym S, const int32_t* __re
 // written with agent-scope (write-through) stores and read with agent-scope (cache-bypassing) loads, the
 // producer drains its stores (s_waitcnt vmcnt(0)) before the barrier that precedes the flag store, and the
 // panels of L keep using ordinary cached loads.
-// A workgroup only ever waits for workgroups with a LOWER linear id, which the dispatcher starts first, so
-// the grid needs no co-residency guarantee; the wait is bounded (err flag) so every wave always exits.
+// A workgroup takes its chain position from an atomic TICKET drawn when it starts (not from blockIdx: HIP does not
+// promise a dispatch order across XCDs / priorities / concurrent kernels).  It only ever waits for positions with a
+// lower ticket, whose workgroups have therefore already started and cannot be starved by it: no co-residency
+// requirement (decoupled look-back argument); the wait is bounded as well (err flag), so every wave always exits.
 // The L fragments are read straight from global memory into the MFMA A operand BEFORE the wait: only the
 // 128 x 32 x-window of the block just finished is on the critical path.
 struct ChainPair {
@@ -1588,14 +1590,25 @@ __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_read
 __device__ __forceinline__ bool chain_wait(const int32_t* flag, int32_t epoch, int32_t* err, int behind) {
   // one thread spins; returns false on timeout / earlier error (the caller then leaves quietly).  `behind` = how
   // many more blocks this workgroup has to wait for after this one: only the workgroups next in line poll
-  // tightly, the others mostly sleep (a few hundred pollers on two dozen flag lines slow every hop down)
+  // tightly, the others mostly sleep (a few hundred pollers on two dozen flag lines slow every hop down).
+  // Timeout = no workgroup of the sweep has published anything for ~1 s of wall clock (err[1] counts published
+  // windows; a healthy sweep publishes one every few microseconds), so a long sweep is never cut short and a
+  // stuck one releases its CUs after a second.
   int spins = 0;
+  int32_t seen = __hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long t_seen = wall_clock64();  // 100 MHz constant-rate counter
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
     if (behind == 0) __builtin_amdgcn_s_sleep(1);
     else
       for (int z = 0; z < min(behind, 8); ++z) __builtin_amdgcn_s_sleep(127);
-    if ((++spins & 1023) == 0) {
-      if (spins > (1 << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    if ((++spins & 255) == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      const int32_t now = __hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t = wall_clock64();
+      if (now != seen) {
+        seen = now;
+        t_seen = t;
+      } else if (t - t_seen > 100000000ull) {
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
@@ -1618,12 +1631,14 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
                                                const int32_t* __restrict__ pair_ptr, const ChainPair* __restrict__ pairs,
                                                const int32_t* __restrict__ colmap, const double* __restrict__ L,
                                                const double* __restrict__ invD, const double* W, double* X, int32_t rp,
-                                               int32_t ncw, int32_t* flags, int32_t epoch, int32_t* err) {
+                                               int32_t ncw, int32_t* flags, int32_t epoch, int32_t* err, int32_t* ticket) {
   __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // x window of the other block, then w_i: [k][c]
-  __shared__ int s_ok, s_ready;
+  __shared__ int s_ok, s_ready, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int32_t lin = blockIdx.x;
+  if (tid == 0) s_ticket = atomicAdd(ticket, 1);  // chain position = order of ARRIVAL on the device
+  __syncthreads();
+  const int32_t lin = s_ticket;
   const int32_t ord = lin / ncw, c = lin - ord * ncw;
   const int32_t i = BWD ? T - 1 - ord : ord;
   const int c_lo = c * CW;
@@ -1855,7 +1870,10 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
   __syncthreads();
   CPROF(5);  // all waves drained
-  if (tid == 0 && ok) __hip_atomic_store(flags + (int64_t)i * ncw + c, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && ok) {
+    __hip_atomic_store(flags + (int64_t)i * ncw + c, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(err + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // progress beacon for the waiters' timeout
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

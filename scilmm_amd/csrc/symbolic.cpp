@@ -129,6 +129,52 @@ void column_counts(int32_t n, const std::vector<int32_t>& parent, const std::vec
 
 }  // namespace
 
+// Fill statistics of the Cholesky factor of a symmetric pattern under a given permutation (perm[new] = old):
+// elimination tree + skeleton column counts only (no supernodes, no schedules).  Used by the ordering study and by
+// the nested-dissection code to compare candidate orderings.
+void fill_count(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, const int32_t* perm, int64_t* nnzL, double* flops,
+                int32_t* max_cc, int32_t* colcount_out) {
+  std::vector<int32_t> iperm(n);
+  for (int32_t i = 0; i < n; ++i) iperm[perm ? perm[i] : i] = i;
+  std::vector<int64_t> cptr(n + 1, 0), rptr;
+  std::vector<int32_t> cidx, ridx;
+  for (int32_t i = 0; i < n; ++i)
+    for (int64_t e = g_ptr[i]; e < g_ptr[i + 1]; ++e) {
+      const int32_t j = g_idx[e];
+      if (j < 0 || j >= n || j >= i) continue;  // each undirected edge once (from its larger endpoint)
+      cptr[std::min(iperm[i], iperm[j]) + 1]++;
+    }
+  for (int32_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
+  cidx.resize(cptr[n]);
+  {
+    std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = g_ptr[i]; e < g_ptr[i + 1]; ++e) {
+        const int32_t j = g_idx[e];
+        if (j < 0 || j >= n || j >= i) continue;
+        const int32_t a = iperm[i], b = iperm[j];
+        cidx[fill[std::min(a, b)]++] = std::max(a, b);
+      }
+  }
+  transpose_pattern(n, cptr, cidx, rptr, ridx);
+  std::vector<int32_t> parent, post, cc;
+  etree(n, rptr, ridx, parent);
+  postorder(n, parent, post);
+  column_counts(n, parent, post, cptr, cidx, cc);
+  int64_t nz = 0;
+  double fl = 0;
+  int32_t mx = 0;
+  for (int32_t j = 0; j < n; ++j) {
+    nz += cc[j];
+    fl += (double)cc[j] * (double)cc[j];
+    mx = std::max(mx, cc[j]);
+  }
+  if (nnzL) *nnzL = nz;
+  if (flops) *flops = fl;
+  if (max_cc) *max_cc = mx;
+  if (colcount_out) std::memcpy(colcount_out, cc.data(), sizeof(int32_t) * (size_t)n);
+}
+
 Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const SymbolicOptions& opts) {
   Symbolic* S = new Symbolic();

@@ -13,6 +13,9 @@ namespace scilmm {
 
 void amd_order(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, int32_t* perm_out, double dense_factor);
 
+void fill_count(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, const int32_t* perm, int64_t* nnzL, double* flops,
+                int32_t* max_cc, int32_t* colcount_out);
+
 struct SymbolicOptions {
   int32_t ordering = 0;        // 0 = AMD, 1 = natural, 2 = user permutation
   int32_t relax_small = 4;     // always merge a child when the merged width is <= this

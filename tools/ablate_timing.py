@@ -1,4 +1,5 @@
 """Timing-only runs of the factorization with diagnostic ablations (SCILMM_ABLATE); results are NOT valid numbers.
+Needs a diagnostic build (make -C scilmm_amd/csrc DIAG=1) and SCILMM_TUNING=1.
 usage: SCILMM_ABLATE=3 SCILMM_NO_LOOKAHEAD=1 python tools/ablate_timing.py"""
 import ctypes as C
 import sys
