@@ -37,12 +37,15 @@ typedef struct scilmm_factor scilmm_factor;     /* numeric factor L of V[P][:,P]
  * SparseCholesky(use_long=False, mode='supernodal', ordering_method='nesdis') (SparseCholesky.py:17-20).
  * Negative / zero fields mean "library default". */
 typedef struct scilmm_options {
-  int32_t ordering;     /* 0 = approximate minimum degree, 1 = natural, 2 = perm_in */
+  int32_t ordering;     /* 0 = approximate minimum degree, 1 = natural, 2 = perm_in, 3 = nested dissection ('nesdis',
+                           SparseCholesky.py:17), 4 = whichever of 0 / 3 gives fewer factor flops */
   int32_t relax_small;  /* relaxed amalgamation: always merge when merged width <= this */
   int32_t relax_w1, relax_w2;
   double relax_z1, relax_z2, relax_z3;
   double amd_dense;
   int32_t max_width;    /* split supernodes wider than this (0 = library default) */
+  double nd_oksep;      /* nested dissection: accept a separator only below this share of its subgraph (0 = default 0.1;
+                           1.0 = always dissect, CHOLMOD's nd_oksep default) */
 } scilmm_options;
 
 typedef struct scilmm_info {
@@ -72,7 +75,8 @@ void scilmm_symbolic_free(scilmm_symbolic* sym);
 
 /* The ordering step of cholmod_analyze alone (SparseCholesky.py:17 ordering_method): fill-reducing permutation of a
  * symmetric CSR pattern (only entries with column < row are read).  method 0 = approximate minimum degree,
- * 1 = nested dissection (graph bisection, minimum degree on the leaves).  perm_out[new] = old. */
+ * 1 = nested dissection (graph bisection, minimum degree on the leaves and wherever no separator below 10 % of the
+ * subgraph exists), 2 = nested dissection that accepts every separator.  perm_out[new] = old. */
 int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32_t method, int32_t* perm_out);
 /* nnz(L), sum colcount^2 and the largest column count of the factor of pattern[perm][:,perm] (perm NULL = natural):
  * elimination tree + column counts only -- what the ordering study in profiles/ and bench.py's fill figures use. */

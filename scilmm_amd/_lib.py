@@ -29,11 +29,12 @@ class NotPositiveDefiniteError(ScilmmError):
 class Options(C.Structure):
     _fields_ = [("ordering", C.c_int32), ("relax_small", C.c_int32), ("relax_w1", C.c_int32),
                 ("relax_w2", C.c_int32), ("relax_z1", C.c_double), ("relax_z2", C.c_double),
-                ("relax_z3", C.c_double), ("amd_dense", C.c_double), ("max_width", C.c_int32)]
+                ("relax_z3", C.c_double), ("amd_dense", C.c_double), ("max_width", C.c_int32),
+                ("nd_oksep", C.c_double)]
 
     @classmethod
     def default(cls, ordering=0, **kw):
-        o = cls(ordering, -1, -1, -1, -1.0, -1.0, -1.0, 0.0, 0)
+        o = cls(ordering, -1, -1, -1, -1.0, -1.0, -1.0, 0.0, 0, 0.0)
         for k, v in kw.items():
             setattr(o, k, v)
         return o
@@ -148,7 +149,7 @@ def symbolic_get(sym, name):
     return out
 
 
-ORDER_METHODS = {"amd": 0, "nesdis": 1}
+ORDER_METHODS = {"amd": 0, "nesdis": 1, "nesdis_always": 2}
 
 
 def order(A, method="amd"):

@@ -25,6 +25,7 @@ int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, c
     if (opts->relax_z3 >= 0) o.relax_z3 = opts->relax_z3;
     if (opts->amd_dense != 0) o.amd_dense = opts->amd_dense;
     if (opts->max_width != 0) o.max_width = opts->max_width < 0 ? 0 : opts->max_width;
+    if (opts->nd_oksep > 0) o.nd_oksep = opts->nd_oksep;
   }
   if (perm_in && !opts) o.ordering = 2;
   scilmm_symbolic* h = new scilmm_symbolic();
@@ -64,6 +65,7 @@ int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
 
 int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, int64_t* count) {
   if (!h || !h->S || !what || !count) return SCILMM_ERR_ARG;
+  if (!h->S->combos_built && !std::strncmp(what, "combo_", 6)) scilmm::build_tile_combos(h->S, nullptr);
   const Symbolic& S = *h->S;
   GET("perm", perm)
   GET("iperm", iperm)
@@ -128,6 +130,12 @@ int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32
   }
   if (method == 0) {
     scilmm::amd_order(n, gptr.data(), gidx.data(), perm_out, 10.0);
+    return SCILMM_OK;
+  }
+  if (method == 1 || method == 2) {  // 1: nested dissection with the default acceptance threshold; 2: always dissect
+    scilmm::NdOptions o;
+    if (method == 2) o.oksep = 1.0;
+    scilmm::nd_order(n, gptr.data(), gidx.data(), perm_out, o, nullptr);
     return SCILMM_OK;
   }
   return SCILMM_ERR_ARG;

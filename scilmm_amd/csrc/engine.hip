@@ -102,6 +102,14 @@ struct Dev {
   int32_t* d_trsm_split = nullptr;      // per split level: critical tiles, then the rest
   std::vector<int64_t> trsm_sptr;       // [2 nlevels + 1]
   std::vector<hipEvent_t> chain_ev;     // 3 per level: potrf done, rest-stream late update done, critical trsm done
+  // multi-GPU: the dense chain at the top of the block etree (levels >= dist_l0, one front each) is owned 1-D
+  // block-cyclically; a rank plans / computes only its own chain panels and receives the others by broadcast
+  int32_t rank = 0, world = 1;
+  int32_t dist_l0 = 0;                  // first level of the distributed chain (nlevels when world == 1)
+  std::vector<uint8_t> keep_front;      // [nsuper] this rank computes the panel of front s
+  std::vector<uint8_t> own_level;       // [nlevels] this rank runs the kernels of level l
+  hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
+  std::vector<hipEvent_t> done_ev;      // per level: kernels of an owned chain level finished (main stream)
   int look_depth = 2;      // "late" = descendants at most this many levels below the target; older ones are "early"
   int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
@@ -200,6 +208,8 @@ void dev_free(void* p) {
   for (auto& e : D->chain_ev)
     if (e) (void)hipEventDestroy(e);
   if (D->stream) (void)hipStreamDestroy(D->stream);
+  for (auto& e : D->done_ev)
+    if (e) (void)hipEventDestroy(e);
   delete D;
 }
 
@@ -462,6 +472,32 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
 #endif
   const char* uv = tune_env("SCILMM_UPDATE_VARIANT");
   if (uv) D->update_variant = atoi(uv);
+  // ---- multi-GPU ownership: the trailing run of single-front levels is the distributed chain
+  D->rank = sym->rank;
+  D->world = std::max<int32_t>(1, sym->world);
+  D->comm = (hipStream_t)sym->comm_stream;
+  D->dist_l0 = S.nlevels;
+  D->keep_front.assign((size_t)std::max(S.nsuper, 1), 1);
+  D->own_level.assign((size_t)std::max(S.nlevels, 1), 1);
+  if (D->world > 1) {
+    int32_t l0 = S.nlevels;
+    while (l0 > 0 && S.level_ptr[l0] - S.level_ptr[l0 - 1] == 1) --l0;
+    D->dist_l0 = l0;
+    for (int32_t l = l0; l < S.nlevels; ++l) {
+      const bool mine = ((l - l0) % D->world) == D->rank;
+      D->own_level[l] = mine ? 1 : 0;
+      D->keep_front[S.level_fronts[S.level_ptr[l]]] = mine ? 1 : 0;
+    }
+    D->done_ev.assign((size_t)std::max(S.nlevels, 1), nullptr);
+    for (int32_t l = l0; l < S.nlevels; ++l) HIPCHK(hipEventCreateWithFlags(&D->done_ev[l], hipEventDisableTiming));
+    if (pverb)
+      fprintf(stderr, "[scilmm plan] rank %d of %d: distributed chain = levels %d..%d (%d panels, every %d-th one mine)\n", D->rank,
+              D->world, l0, S.nlevels - 1, S.nlevels - l0, D->world);
+  }
+  if (!sym->S->combos_built) {
+    scilmm::build_tile_combos(sym->S, D->world > 1 ? D->keep_front.data() : nullptr);
+    plap("tile combos");
+  }
   D->v.n = S.n;
   D->v.nsuper = S.nsuper;
   int st;
@@ -531,6 +567,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     {
       const char* eld = tune_env("SCILMM_LOOK_DEPTH");
       D->look_depth = eld ? std::max(1, atoi(eld)) : 2;  // measured at 100k: depth 1 81.4 ms, 2 77.6 ms, 3 78.4 ms
+      // multi-GPU: a rank owns every world-th chain panel; everything older than its previous own panel is "early"
+      // work that needs nothing still in flight, the last `world` source panels are applied as they arrive
+      if (D->world > 1 && !eld) D->look_depth = std::max(2, D->world);
     }
     const int32_t depth = D->look_depth;
     D->split_lv.assign(std::max(S.nlevels, 1), 0);
@@ -541,7 +580,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       // under the saturating early updates both run ~1.6x slower than isolated.
       const char* ens = tune_env("SCILMM_SPLIT_CHAIN");
       const char* ecp = tune_env("SCILMM_COMPACT");
-      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1');
+      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1') && D->world == 1;
       int64_t why[3] = {0, 0, 0};
       for (int32_t l = 1; allow && l + 1 < S.nlevels; ++l) {
         if (S.level_ptr[l + 1] - S.level_ptr[l] != 1 || S.level_ptr[l + 2] - S.level_ptr[l + 1] != 1) continue;
@@ -922,6 +961,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       int64_t slots = 0;
       // a split level lists its diagonal tile first: the late items / reduce entries of that tile lead the level
       std::vector<int32_t> order(S.level_tiles.begin() + S.level_tile_ptr[l], S.level_tiles.begin() + S.level_tile_ptr[l + 1]);
+      // heaviest tiles (most combos) first: the long items of a launch start early
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (S.combo_ptr[a + 1] - S.combo_ptr[a]) > (S.combo_ptr[b + 1] - S.combo_ptr[b]);
+      });
       if (D->split_lv[l]) {
         const int32_t g0 = (int32_t)S.tile_base[S.level_fronts[S.level_ptr[l]]];
         auto it = std::find(order.begin(), order.end(), g0);
@@ -1285,6 +1328,7 @@ struct scilmm_factor {
   double* logd = nullptr;
   int32_t* status = nullptr;
   bool valid = false;
+  bool external = false;      // L / invD / logd belong to the caller (scilmm_factor_create_external)
   bool pending = false;       // a factorization has been queued (scilmm_refactorize_async) and not yet waited for
   int32_t* h_status = nullptr;  // pinned host copy of *status, filled by the queued copy
 };
@@ -1307,6 +1351,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       return SCILMM_ERR_STATE;
     }
   fac->valid = false;
+  if (D->world > 1 && (!sym->comm_fn || !D->comm)) {
+    sym->err = "multi-GPU: scilmm_dist_init was called without a communication callback / stream";
+    return SCILMM_ERR_STATE;
+  }
   {
     int stc = set_attrs(sym, D);
     if (stc != SCILMM_OK) return stc;
@@ -1405,7 +1453,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   auto launch_early = [&](int32_t l) -> int {
     const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
     if (!has_early(l)) return SCILMM_OK;
-    const int sidx = l % D->nside;
+    // (multi-GPU: a rank's own chain levels are `world` apart -- alternate the side streams over ITS levels)
+    const int sidx = (D->world > 1 && l >= D->dist_l0) ? ((l - D->dist_l0) / D->world) % D->nside : l % D->nside;
     hipStream_t sd = sidx == 0 ? D->side : (sidx == 1 ? D->side2 : D->side3);
     // its youngest descendants sit look_depth + 1 levels below
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
@@ -1485,26 +1534,56 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     };
     // a level that follows a split level: its predecessor's tail (the other tiles' trsm) ended on the rest stream
     const bool prev_split = l >= 1 && D->split_lv[l - 1];
+    const bool dist_chain = D->world > 1 && l >= D->dist_l0;
     if (!D->split_lv[l]) {
-      if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
-      if (prev_split) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - 1)], 0));
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
-      if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
-      if (D->compact_mode == 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l], sh);
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
-      launch_reduce(st, r0, r1);
-      if (D->compact_mode != 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
-      launch_cells(st, 1, l);
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
-      if (f1 > f0) {
-        hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
-                           fac->invD, fac->logd, fac->status);
-        launches++;
+      if (D->own_level[l]) {
+        if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
+        if (prev_split) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - 1)], 0));
+        if (dist_chain) {
+          // the late items read the panels of the last look_depth levels, which other ranks produced: wait for
+          // their arrival (events of the comm stream; for this rank's own older panels the wait is a no-op)
+          for (int32_t back = 1; back <= D->look_depth && back <= l; ++back) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - back)], 0));
+        }
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
+        if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+        if (D->compact_mode == 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l], sh);
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
+        launch_reduce(st, r0, r1);
+        if (D->compact_mode != 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
+        launch_cells(st, 1, l);
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
+        if (f1 > f0) {
+          hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
+                             fac->invD, fac->logd, fac->status);
+          launches++;
+        }
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
+        launch_trsm(st, D->d_level_tiles + t0, t1 - t0);
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
+      } else if (prof) {
+        for (int q = 0; q < 5; ++q) HIPCHK(hipEventRecord(D->pev[PE * l + q], st));
       }
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
-      launch_trsm(st, D->d_level_tiles + t0, t1 - t0);
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
-      HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
+      if (!dist_chain) {
+        HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
+      } else {
+        // ---- distributed chain level: the owner's panel (+ inverse diagonal block + log-sum) goes to every rank
+        const int32_t sfr = S.level_fronts[f0];
+        const int32_t root = (l - D->dist_l0) % D->world;
+        if (l == D->dist_l0 && l > 0) HIPCHK(hipStreamWaitEvent(D->comm, D->lev_ev[2 * (l - 1)], 0));  // local prelude (and assembly) complete
+        if (D->own_level[l]) {
+          HIPCHK(hipEventRecord(D->done_ev[l], st));
+          HIPCHK(hipStreamWaitEvent(D->comm, D->done_ev[l], 0));
+        }
+        const int64_t pm = S.sn_rowptr[sfr + 1] - S.sn_rowptr[sfr], pw = S.sn_start[sfr + 1] - S.sn_start[sfr];
+        int rcm = sym->comm_fn(sym->comm_ctx, 0, 0, S.sn_loff[sfr], pm * pw, root);
+        if (rcm == 0) rcm = sym->comm_fn(sym->comm_ctx, 0, 1, S.inv_off[sfr], pw * pw, root);
+        if (rcm == 0) rcm = sym->comm_fn(sym->comm_ctx, 0, 2, sfr, 1, root);
+        if (rcm != 0) {
+          sym->err = "multi-GPU: the communication callback failed";
+          return SCILMM_ERR_DEVICE;
+        }
+        HIPCHK(hipEventRecord(D->lev_ev[2 * l], D->comm));
+      }
     } else {
       // ---- split chain level.  Main stream: late update of the diagonal tile, potrf, then trsm of the tiles the
       //      NEXT diagonal block is updated from.  Rest stream: late update of the other tiles, then their trsm.
@@ -1546,6 +1625,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       HIPCHK(hipEventRecord(D->lev_ev[2 * l], rs));
     }
   }
+  if (D->world > 1 && S.nlevels > D->dist_l0) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (S.nlevels - 1)], 0));
   HIPCHK(hipEventRecord(D->ev[2], st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(fac->h_status, fac->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1571,6 +1651,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   HIPCHK(hipStreamSynchronize(D->rest));
   for (auto& cs : D->cside)
     if (cs) HIPCHK(hipStreamSynchronize(cs));
+  if (D->world > 1 && D->comm) HIPCHK(hipStreamSynchronize(D->comm));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));

@@ -266,7 +266,27 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         gidx[fill[i]++] = j;
         gidx[fill[j]++] = i;
       }
-    amd_order(n, gptr.data(), gidx.data(), perm.data(), opts.amd_dense);
+    if (opts.ordering == 3 || opts.ordering == 4) {
+      NdOptions ndo;
+      ndo.oksep = opts.nd_oksep;
+      NdStats nds;
+      nd_order(n, gptr.data(), gidx.data(), perm.data(), ndo, &nds);
+      if (verbose)
+        fprintf(stderr, "[scilmm symbolic] nested dissection: %d -> %d compressed vertices, %lld separators, largest %lld\n", n,
+                nds.n_compressed, (long long)nds.n_separators, (long long)nds.top_separator);
+      if (opts.ordering == 4) {
+        // keep whichever ordering gives fewer factor flops (elimination tree + column counts only: cheap)
+        std::vector<int32_t> p2(n);
+        amd_order(n, gptr.data(), gidx.data(), p2.data(), opts.amd_dense);
+        double f_nd = 0, f_amd = 0;
+        fill_count(n, gptr.data(), gidx.data(), perm.data(), nullptr, &f_nd, nullptr, nullptr);
+        fill_count(n, gptr.data(), gidx.data(), p2.data(), nullptr, &f_amd, nullptr, nullptr);
+        if (verbose) fprintf(stderr, "[scilmm symbolic] factor flops: nested dissection %.4g, minimum degree %.4g\n", f_nd, f_amd);
+        if (f_amd < f_nd) perm.swap(p2);
+      }
+    } else {
+      amd_order(n, gptr.data(), gidx.data(), perm.data(), opts.amd_dense);
+    }
   }
   std::vector<int32_t> iperm(n);
   for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
@@ -623,7 +643,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     for (int32_t s = 0; s < ns; ++s) S->level_fronts[fill[S->sn_level[s]]++] = s;
   }
   lap("update schedule");
-  // ---------------------------------------------------------------- 11. target tiles and their combos
+  // ---------------------------------------------------------------- 11. target tiles (their combos are built lazily)
   {
     const int32_t TM = opts.tile_rows;
     S->tile_rows = TM;
@@ -636,6 +656,37 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     S->tile_front.resize(nt);
     for (int32_t s = 0; s < ns; ++s)
       for (int64_t g = S->tile_base[s]; g < S->tile_base[s + 1]; ++g) S->tile_front[g] = s;
+    // per-level tile lists in tile order (the update plan balances its own work items; trsm / L*R tiles cost the same)
+    S->level_tile_ptr.assign(S->nlevels + 1, 0);
+    for (int64_t g = 0; g < nt; ++g) S->level_tile_ptr[S->sn_level[S->tile_front[g]] + 1]++;
+    for (int32_t l = 0; l < S->nlevels; ++l) S->level_tile_ptr[l + 1] += S->level_tile_ptr[l];
+    S->level_tiles.resize(nt);
+    {
+      std::vector<int64_t> fill(S->level_tile_ptr.begin(), S->level_tile_ptr.end() - 1);
+      for (int64_t g = 0; g < nt; ++g) S->level_tiles[fill[S->sn_level[S->tile_front[g]]]++] = (int32_t)g;
+    }
+    // per-level update-pair lists (by target level)
+    S->level_pair_ptr.assign(S->nlevels + 1, 0);
+    for (int32_t s = 0; s < ns; ++s) S->level_pair_ptr[S->sn_level[s] + 1] += S->upd_ptr[s + 1] - S->upd_ptr[s];
+    for (int32_t l = 0; l < S->nlevels; ++l) S->level_pair_ptr[l + 1] += S->level_pair_ptr[l];
+    S->level_pairs.resize(S->upd_src.size());
+    {
+      std::vector<int64_t> fill(S->level_pair_ptr.begin(), S->level_pair_ptr.end() - 1);
+      for (int32_t s = 0; s < ns; ++s)
+        for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) S->level_pairs[fill[S->sn_level[s]]++] = (int32_t)e;
+    }
+  }
+  return S;
+}
+
+// Step 11b, on demand: for every 128-row tile of every target panel the list of descendant row ranges ("combos")
+// that land in it.  keep_front (optional, [nsuper]) restricts the enumeration to the targets a rank owns in a
+// multi-GPU run; the lists of the other tiles stay empty.
+void build_tile_combos(Symbolic* S, const uint8_t* keep_front) {
+  const int32_t ns = S->nsuper;
+  const int32_t TM = S->tile_rows;
+  const int64_t nt = S->tile_base[ns];
+  {
     // pass 1: count combos per tile, pass 2: fill. Rows of d beyond p0 are merged against rows of s.
     std::vector<int64_t> cnt(nt + 1, 0);
     for (int pass = 0; pass < 2; ++pass) {
@@ -651,6 +702,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       }
 #pragma omp parallel for schedule(dynamic, 64)
       for (int32_t s = 0; s < ns; ++s) {
+        if (keep_front && !keep_front[s]) continue;
         const int32_t* rs = S->sn_rows.data() + S->sn_rowptr[s];
         int64_t ms = S->sn_rowptr[s + 1] - S->sn_rowptr[s];
         for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) {
@@ -683,33 +735,8 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         }
       }
     }
-    lap("tile combos");
-    // per-level tile lists, heaviest (most combos) first for load balance
-    S->level_tile_ptr.assign(S->nlevels + 1, 0);
-    for (int64_t g = 0; g < nt; ++g) S->level_tile_ptr[S->sn_level[S->tile_front[g]] + 1]++;
-    for (int32_t l = 0; l < S->nlevels; ++l) S->level_tile_ptr[l + 1] += S->level_tile_ptr[l];
-    S->level_tiles.resize(nt);
-    {
-      std::vector<int64_t> fill(S->level_tile_ptr.begin(), S->level_tile_ptr.end() - 1);
-      for (int64_t g = 0; g < nt; ++g) S->level_tiles[fill[S->sn_level[S->tile_front[g]]]++] = (int32_t)g;
-      for (int32_t l = 0; l < S->nlevels; ++l)
-        std::stable_sort(S->level_tiles.begin() + S->level_tile_ptr[l], S->level_tiles.begin() + S->level_tile_ptr[l + 1],
-                         [&](int32_t a, int32_t b) {
-                           return (S->combo_ptr[a + 1] - S->combo_ptr[a]) > (S->combo_ptr[b + 1] - S->combo_ptr[b]);
-                         });
-    }
-    // per-level update-pair lists (by target level)
-    S->level_pair_ptr.assign(S->nlevels + 1, 0);
-    for (int32_t s = 0; s < ns; ++s) S->level_pair_ptr[S->sn_level[s] + 1] += S->upd_ptr[s + 1] - S->upd_ptr[s];
-    for (int32_t l = 0; l < S->nlevels; ++l) S->level_pair_ptr[l + 1] += S->level_pair_ptr[l];
-    S->level_pairs.resize(S->upd_src.size());
-    {
-      std::vector<int64_t> fill(S->level_pair_ptr.begin(), S->level_pair_ptr.end() - 1);
-      for (int32_t s = 0; s < ns; ++s)
-        for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) S->level_pairs[fill[S->sn_level[s]]++] = (int32_t)e;
-    }
   }
-  return S;
+  S->combos_built = true;
 }
 
 }  // namespace scilmm

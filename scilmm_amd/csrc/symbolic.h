@@ -13,11 +13,25 @@ namespace scilmm {
 
 void amd_order(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, int32_t* perm_out, double dense_factor);
 
+struct NdOptions {
+  int64_t leaf_weight = 200;  // subgraphs of at most this many (uncompressed) vertices are ordered by minimum degree
+  double oksep = 0.1;         // accept a separator only if its weight is below oksep * subgraph weight (else: AMD)
+  double balance = 0.6;       // neither side of the edge bisection may exceed this share of the weight
+  int32_t tries = 4;          // greedy-growing starts per bisection
+  uint64_t seed = 1;
+};
+struct NdStats {
+  int32_t n_compressed = 0;
+  int64_t edges_compressed = 0, n_separators = 0, top_separator = 0;
+};
+void nd_order(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, int32_t* perm_out, const NdOptions& opt, NdStats* stats);
+
 void fill_count(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, const int32_t* perm, int64_t* nnzL, double* flops,
                 int32_t* max_cc, int32_t* colcount_out);
 
 struct SymbolicOptions {
-  int32_t ordering = 0;        // 0 = AMD, 1 = natural, 2 = user permutation
+  int32_t ordering = 0;        // 0 = AMD, 1 = natural, 2 = user permutation, 3 = nested dissection, 4 = better of AMD / ND
+  double nd_oksep = 0.1;       // nested dissection: separator acceptance threshold (1.0 = always dissect)
   int32_t relax_small = 4;     // always merge a child when the merged width is <= this
   int32_t relax_w1 = 16;       // merged width <= relax_w1 -> allow zero fraction z1
   int32_t relax_w2 = 48;       // merged width <= relax_w2 -> allow zero fraction z2
@@ -60,12 +74,13 @@ struct Symbolic {
   std::vector<int64_t> tile_base;   // [nsuper+1] first global tile id of each front
   std::vector<int32_t> tile_front;  // [ntiles] owning front
   std::vector<int64_t> combo_ptr;   // [ntiles+1]
+  bool combos_built = false;        // combo_* are filled on demand by build_tile_combos()
   std::vector<int32_t> combo_pair;  // index into upd_src/upd_p0/upd_p1
   std::vector<int32_t> combo_ta, combo_tb;
   std::vector<int32_t> combo_ip0;   // tile position of row ta when rows ta..tb land on consecutive positions, else -1
   std::vector<int32_t> upd_jp0;     // [npairs] target column of row p0 when rows p0..p1 are consecutive columns, else -1
   std::vector<int64_t> level_tile_ptr; // [nlevels+1] tiles of level l are level_tiles[ptr[l]..ptr[l+1])
-  std::vector<int32_t> level_tiles;    // global tile ids sorted by level (heaviest first)
+  std::vector<int32_t> level_tiles;    // global tile ids grouped by level (tile order)
   std::vector<int64_t> level_pair_ptr; // [nlevels+1] update pairs whose TARGET is in level l
   std::vector<int32_t> level_pairs;
   // level schedule: fronts sorted by (level, size class)
@@ -96,5 +111,9 @@ struct Symbolic {
 // perm_in: optional user permutation (perm_in[new] = old), required when opts.ordering == 2.
 Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const SymbolicOptions& opts);
+
+// Fills Symbolic::combo_* (step 11b of the analysis).  keep_front: optional [nsuper] mask of the target fronts whose
+// tiles are enumerated (multi-GPU: the targets this rank owns); NULL = all.
+void build_tile_combos(Symbolic* S, const uint8_t* keep_front);
 
 }  // namespace scilmm

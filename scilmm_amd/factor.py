@@ -14,7 +14,7 @@ import scipy.sparse as sp
 from . import _lib
 from ._lib import check, lib, ptr
 
-_ORDERINGS = {"amd": 0, "natural": 1, "given": 2}
+_ORDERINGS = {"amd": 0, "natural": 1, "given": 2, "nesdis": 3, "best": 4}
 
 
 def _as_csr(m):
