@@ -100,6 +100,23 @@ int scilmm_refactorize_async(scilmm_factor* fac, const double* sigma2);
 int scilmm_factor_wait(scilmm_factor* fac, int32_t* bad_col);
 void scilmm_factor_free(scilmm_factor* fac);
 
+/* --- multi-GPU: one process per GPU.  The dense chain at the top of the block elimination tree
+ * (the separator supernodes: >99 % of the flops of a pedigree factor) is distributed 1-D block-cyclically: a rank
+ * computes every world-th chain panel and receives the others.  The library does not link a communication
+ * library: it calls `fn` at ENQUEUE time, in the same order on every rank, and the callback issues the collective
+ * on `comm_stream` (torch.distributed over RCCL in production, gloo in the CPU/1-GPU rehearsals):
+ *   op 0 = broadcast from `root`;  buffer 0 = L, 1 = invD, 2 = logd (the arrays given to
+ *   scilmm_factor_create_external);  offset / count in doubles.
+ * The engine orders its own streams against `comm_stream` with events (before the call: comm_stream waits for the
+ * owner's kernels; after it: an event recorded on comm_stream releases the consumers).  Must be called before the
+ * first numeric call on the handle.  The reference has no counterpart (single-process CHOLMOD). */
+typedef int (*scilmm_comm_fn)(void* ctx, int32_t op, int32_t buffer, int64_t offset, int64_t count, int32_t root);
+int scilmm_dist_init(scilmm_symbolic* sym, int32_t rank, int32_t world, void* comm_stream, scilmm_comm_fn fn, void* ctx);
+/* Factor storage owned by the caller (so that the communication layer can address it, e.g. as torch tensors):
+ * sizes in doubles incl. the slack the kernels over-read; then create the handle and use scilmm_refactorize. */
+int scilmm_factor_sizes(const scilmm_symbolic* sym, int64_t* L_doubles, int64_t* invD_doubles, int64_t* logd_doubles);
+int scilmm_factor_create_external(scilmm_symbolic* sym, double* L, double* invD, double* logd, scilmm_factor** out);
+
 /* factor.logdet()  (SparseCholesky.py:40) */
 int scilmm_logdet(scilmm_factor* fac, double* out);
 /* factor(b): X = V^{-1} B, B and X row-major n x r  (SparseCholesky.py:30,32,52,100,149,153) */

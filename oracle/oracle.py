@@ -57,6 +57,8 @@ def lib():
         L.sncpu_factorize.restype = C.c_int
         L.sncpu_factorize.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
         L.sncpu_solve.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp]
+        L.sncpu_factorize_range.restype = C.c_int
+        L.sncpu_factorize_range.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
         _lib = L
     return _lib
 
@@ -243,8 +245,32 @@ class SupernodalCPU(object):
         if st != 0:
             raise NotPositiveDefinite(st - 1)
 
+    def factorize_range(self, s0, s1):
+        """Panels of supernodes [s0, s1) only; their descendants must be final in self.Lx (oracle/dist_cpu.py)."""
+        a = self.a
+        st = lib().sncpu_factorize_range(s0, s1, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_rows"]), _p(a["sn_loff"]),
+                                         _p(a["upd_ptr"]), _p(a["upd_src"]), _p(a["upd_p0"]), _p(a["upd_p1"]), self.n,
+                                         _p(self.Lx))
+        if st != 0:
+            raise NotPositiveDefinite(st - 1)
+
     def logdet(self):
         return 2.0 * np.log(self.Lx[self.a["diag_dst"]]).sum()
+
+    def L_csc(self):
+        """The factor as scipy CSC (permuted labels), assembled from the panels."""
+        a = self.a
+        rows, cols, vals = [], [], []
+        for s in range(self.ns):
+            c0, w = int(a["sn_start"][s]), int(a["sn_start"][s + 1] - a["sn_start"][s])
+            rs = a["sn_rows"][a["sn_rowptr"][s]:a["sn_rowptr"][s + 1]]
+            m = rs.size
+            P = self.Lx[a["sn_loff"][s]:a["sn_loff"][s] + m * w].reshape(w, m)  # column-major m x w
+            for j in range(w):
+                rows.append(rs[j:])
+                cols.append(np.full(m - j, c0 + j))
+                vals.append(P[j, j:])
+        return sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.n, self.n))
 
     def solve_permuted(self, Y):
         """Y: (n, r) Fortran-ordered, already permuted; solved in place."""

@@ -32,16 +32,28 @@ void sncpu_set_blas(void* gemm, void* syrk, void* trsm, void* potrf) {
   p_dpotrf = (dpotrf_t)potrf;
 }
 
-/* Lx: panel storage (zeroed + assembled by the caller).  Returns 0 or 1+failing column. */
+/* Lx: panel storage (zeroed + assembled by the caller).  Returns 0 or 1+failing column.
+ * sncpu_factorize_range computes the panels of supernodes [s0, s1) only (their descendants must already be final in
+ * Lx): the unit of work of the multi-rank rehearsal in oracle/dist_cpu.py. */
+int sncpu_factorize_range(int32_t s0, int32_t s1, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows,
+                          const int64_t* sn_loff, const int64_t* upd_ptr, const int32_t* upd_src, const int32_t* upd_p0,
+                          const int32_t* upd_p1, int32_t n, double* Lx);
+
 int sncpu_factorize(int32_t ns, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows,
                     const int64_t* sn_loff, const int64_t* upd_ptr, const int32_t* upd_src, const int32_t* upd_p0,
                     const int32_t* upd_p1, int32_t n, double* Lx) {
+  return sncpu_factorize_range(0, ns, sn_start, sn_rowptr, sn_rows, sn_loff, upd_ptr, upd_src, upd_p0, upd_p1, n, Lx);
+}
+
+int sncpu_factorize_range(int32_t s0, int32_t s1, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows,
+                          const int64_t* sn_loff, const int64_t* upd_ptr, const int32_t* upd_src, const int32_t* upd_p0,
+                          const int32_t* upd_p1, int32_t n, double* Lx) {
   int32_t* pos = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   size_t wcap = 1 << 20;
   double* W = (double*)malloc(sizeof(double) * wcap);
   char N = 'N', T = 'T', Lo = 'L', R = 'R';
   double one = 1.0, zero = 0.0;
-  for (int32_t s = 0; s < ns; ++s) {
+  for (int32_t s = s0; s < s1; ++s) {
     int32_t c0 = sn_start[s], w = sn_start[s + 1] - c0;
     const int32_t* rs = sn_rows + sn_rowptr[s];
     int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);

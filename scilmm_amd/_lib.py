@@ -64,6 +64,7 @@ SYMBOLS = [
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
     "scilmm_order", "scilmm_fill_count",
+    "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external",
 ]
 
 _lib = None
@@ -112,6 +113,9 @@ def lib():
     L.scilmm_ibd_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.scilmm_ibd_free.argtypes = [vp]
     L.scilmm_ibd_free.restype = None
+    L.scilmm_dist_init.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.scilmm_factor_sizes.argtypes = [vp, P(i64), P(i64), P(i64)]
+    L.scilmm_factor_create_external.argtypes = [vp, vp, vp, vp, P(vp)]
     L.scilmm_order.argtypes = [i32, vp, vp, i32, vp]
     L.scilmm_fill_count.argtypes = [i32, vp, vp, vp, P(i64), P(dbl), P(i32)]
     _lib = L
@@ -148,6 +152,8 @@ def symbolic_get(sym, name):
     check(lib().scilmm_symbolic_get(sym, name.encode(), ptr(out), C.byref(n)), sym)
     return out
 
+
+COMM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32)
 
 ORDER_METHODS = {"amd": 0, "nesdis": 1, "nesdis_always": 2}
 

@@ -1989,9 +1989,28 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) 
   return SCILMM_OK;
 }
 
-int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor** out, int32_t* bad_col) {
-  if (!sym || !sym->S || !sigma2 || !out) return SCILMM_ERR_ARG;
-  DevGuard guard(sym);
+// slack behind L and invD: the chain sweeps read whole 4-deep k-steps of a panel / an inverse block and discard the
+// lanes past its last column (at most 3 columns of the tallest panel resp. of an NB-wide block)
+static void factor_sizes(const Symbolic& S, size_t* nL, size_t* padL, size_t* nI, size_t* padI) {
+  int64_t max_m = 0;
+  for (int32_t q = 0; q < S.nsuper; ++q) max_m = std::max<int64_t>(max_m, S.sn_rowptr[q + 1] - S.sn_rowptr[q]);
+  *padL = (size_t)(4 * max_m + 4 * NB);
+  *padI = (size_t)(5 * NB);
+  *nL = (size_t)std::max<int64_t>(S.nnzL_stored, 1);
+  *nI = (size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1);
+}
+
+int scilmm_factor_sizes(const scilmm_symbolic* sym, int64_t* L_doubles, int64_t* invD_doubles, int64_t* logd_doubles) {
+  if (!sym || !sym->S) return SCILMM_ERR_ARG;
+  size_t nL, padL, nI, padI;
+  factor_sizes(*sym->S, &nL, &padL, &nI, &padI);
+  if (L_doubles) *L_doubles = (int64_t)(nL + padL);
+  if (invD_doubles) *invD_doubles = (int64_t)(nI + padI);
+  if (logd_doubles) *logd_doubles = (int64_t)std::max(sym->S->nsuper, 1);
+  return SCILMM_OK;
+}
+
+static int factor_create(scilmm_symbolic* sym, double* L_ext, double* invD_ext, double* logd_ext, scilmm_factor** out) {
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
@@ -1999,20 +2018,53 @@ int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor**
   scilmm_factor* f = new scilmm_factor();
   f->sym = sym;
   *out = f;
-  // slack behind both arrays: the chain sweeps read whole 4-deep k-steps of a panel / an inverse block and
-  // discard the lanes past its last column (at most 3 columns of the tallest panel resp. of an NB-wide block)
-  int64_t max_m = 0;
-  for (int32_t q = 0; q < S.nsuper; ++q) max_m = std::max<int64_t>(max_m, S.sn_rowptr[q + 1] - S.sn_rowptr[q]);
-  const size_t padL = (size_t)(4 * max_m + 4 * NB), padI = (size_t)(5 * NB);
-  HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * ((size_t)std::max<int64_t>(S.nnzL_stored, 1) + padL)));
-  HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * ((size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1) + padI)));
-  HIPCHK(hipMemset(f->L + (size_t)std::max<int64_t>(S.nnzL_stored, 1), 0, sizeof(double) * padL));
+  size_t nL, padL, nI, padI;
+  factor_sizes(S, &nL, &padL, &nI, &padI);
+  if (L_ext) {
+    f->external = true;
+    f->L = L_ext;
+    f->invD = invD_ext;
+    f->logd = logd_ext;
+  } else {
+    HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * (nL + padL)));
+    HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * (nI + padI)));
+    HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
+  }
+  HIPCHK(hipMemset(f->L + nL, 0, sizeof(double) * padL));
   // (all of invD: k_potrf only ever writes the lower triangles, the upper ones must read as zero)
-  HIPCHK(hipMemset(f->invD, 0, sizeof(double) * ((size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1) + padI)));
-  HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
+  HIPCHK(hipMemset(f->invD, 0, sizeof(double) * (nI + padI)));
   HIPCHK(hipMalloc((void**)&f->status, sizeof(int32_t)));
   HIPCHK(hipHostMalloc((void**)&f->h_status, sizeof(int32_t), hipHostMallocDefault));
-  return run_factorize(f, sigma2, bad_col);
+  return SCILMM_OK;
+}
+
+int scilmm_factorize(scilmm_symbolic* sym, const double* sigma2, scilmm_factor** out, int32_t* bad_col) {
+  if (!sym || !sym->S || !sigma2 || !out) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  int st = factor_create(sym, nullptr, nullptr, nullptr, out);
+  if (st != SCILMM_OK) return st;
+  return run_factorize(*out, sigma2, bad_col);
+}
+
+int scilmm_factor_create_external(scilmm_symbolic* sym, double* L, double* invD, double* logd, scilmm_factor** out) {
+  if (!sym || !sym->S || !L || !invD || !logd || !out) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  return factor_create(sym, L, invD, logd, out);
+}
+
+int scilmm_dist_init(scilmm_symbolic* sym, int32_t rank, int32_t world, void* comm_stream, scilmm_comm_fn fn, void* ctx) {
+  if (!sym || !sym->S || world < 1 || rank < 0 || rank >= world) return SCILMM_ERR_ARG;
+  if (sym->device) {
+    sym->err = "scilmm_dist_init must precede the first numeric call on this handle (the device plan depends on it)";
+    return SCILMM_ERR_STATE;
+  }
+  if (world > 1 && (!fn || !comm_stream)) return SCILMM_ERR_ARG;
+  sym->rank = rank;
+  sym->world = world;
+  sym->comm_stream = comm_stream;
+  sym->comm_fn = fn;
+  sym->comm_ctx = ctx;
+  return SCILMM_OK;
 }
 
 int scilmm_refactorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col) {
@@ -2039,9 +2091,11 @@ void scilmm_factor_free(scilmm_factor* fac) {
   DevGuard guard(fac->sym);
   if (fac->pending) (void)finish_factorize(fac, nullptr);
   if (fac->h_status) (void)hipHostFree(fac->h_status);
-  if (fac->L) (void)hipFree(fac->L);
-  if (fac->invD) (void)hipFree(fac->invD);
-  if (fac->logd) (void)hipFree(fac->logd);
+  if (!fac->external) {
+    if (fac->L) (void)hipFree(fac->L);
+    if (fac->invD) (void)hipFree(fac->invD);
+    if (fac->logd) (void)hipFree(fac->logd);
+  }
   if (fac->status) (void)hipFree(fac->status);
   delete fac;
 }
