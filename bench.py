@@ -16,8 +16,10 @@ device plan) is the warm-up, then as many timed steps as fit are run (at least o
 actually run as `steps` / `warmup` and the requested ones as `steps_requested` / `warmup_requested`.  Small
 workloads (--workload 100k) fit the requested counts and run them unchanged.
 
-For N > 1 every rank owns one independent pedigree block of a block-diagonal cohort (components shard with no
-data-path collective; only scalars are all-reduced): weak scaling.  Rank 0 prints one JSON line.
+For N > 1 the N ranks factorize the SAME ONE cohort together (strong scaling, BASELINE configs[3]): the separator
+chain of the block elimination tree -- > 99.9 % of the flops at 1M -- is distributed 1-D block-cyclically, every
+finished chain panel is broadcast from its owner over RCCL/xGMI (scilmm_amd/dist.py), and the 103 right-hand-side
+columns of the solve are split over the ranks and all-gathered.  Rank 0 prints one JSON line.
 """
 import argparse
 import ctypes
@@ -134,24 +136,55 @@ def main():
     from scilmm_amd.factor import Symbolic
     want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     t0 = time.time()
-    # Weak scaling: every rank factorizes its own copy of the SAME simulated cohort (one block of a block-diagonal
-    # population), so the per-GPU work is exactly fixed as N grows.  (Different seeds per rank give factors of
-    # 1.3e8 .. 2.1e8 nonzeros at the 100k config, and max-over-ranks timing would then measure the seed lottery.)
-    A, C, y = build_problem(args.workload, seed=int(os.environ.get("SCILMM_BENCH_SEED", "0")))
+    # One cohort for the whole job.  Rank 0 simulates it and hands it to the other ranks through /dev/shm (N
+    # simultaneous simulations of a 1M pedigree would need N x 40 GB of host memory and N x the cores).
+    seed = int(os.environ.get("SCILMM_BENCH_SEED", "0"))
+    if world == 1:
+        A, C, y = build_problem(args.workload, seed=seed)
+    else:
+        shm = "/dev/shm/scilmm_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), args.workload)
+        if rank == 0:
+            A, C, y = build_problem(args.workload, seed=seed)
+            np.save(shm + "_indptr.npy", A.indptr); np.save(shm + "_indices.npy", A.indices)
+            np.save(shm + "_data.npy", A.data); np.save(shm + "_C.npy", C); np.save(shm + "_y.npy", y)
+        dist.barrier()
+        if rank != 0:
+            C, y = np.load(shm + "_C.npy"), np.load(shm + "_y.npy")
+            A = sp.csr_matrix((np.load(shm + "_data.npy"), np.load(shm + "_indices.npy"), np.load(shm + "_indptr.npy")),
+                              shape=(y.size, y.size))
+        dist.barrier()
+        if rank == 0:
+            for suffix in ("indptr", "indices", "data", "C", "y"):
+                os.remove(shm + "_%s.npy" % suffix)
     n = A.shape[0]
     t_gen = time.time() - t0
     t0 = time.time()
-    sym = Symbolic([A, sp.identity(n, format="csr")])
+    eng = None
+    if world == 1:
+        sym = Symbolic([A, sp.identity(n, format="csr")])
+    else:
+        from scilmm_amd.dist import HipChainEngine, column_chunks
+        eng = HipChainEngine([A, sp.identity(n, format="csr")], rank, world, dist, dev)
+        sym = eng.sym
     t_sym = time.time() - t0
     info = sym.info()
     sym.set_profiling(True)
 
     c, s = C.shape[1], 100
     r = c + 1 + s
-    rng = np.random.default_rng(100 + rank)
+    rng = np.random.default_rng(100)  # the same right-hand sides on every rank
     B_host = np.hstack([C, y[:, None], rng.standard_normal((n, s))])
-    dB = torch.from_numpy(B_host).to(dev)
+    if world == 1:
+        c0r, c1r, wpad = 0, r, r
+    else:
+        chunks = column_chunks(r, world)
+        c0r, c1r = chunks[rank]
+        wpad = max(b - a for a, b in chunks)  # equal-size all-gather: pad every rank's slice to the widest one
+    B_loc = np.zeros((n, wpad))
+    B_loc[:, :c1r - c0r] = B_host[:, c0r:c1r]
+    dB = torch.from_numpy(B_loc).to(dev)
     dX = torch.empty_like(dB)
+    gathered = [torch.empty_like(dX) for _ in range(world)] if world > 1 else None
     torch.cuda.synchronize()
 
     state = {"fac": None}
@@ -161,16 +194,20 @@ def main():
         return [0.4 + 0.01 * (i % 3), 0.6 - 0.01 * (i % 3)]
 
     def step(i):
-        if state["fac"] is None:
-            state["fac"] = sym.factorize(sigma2_of(i))  # the first evaluation also builds the device plan
+        if eng is not None:
+            eng.factorize(sigma2_of(i))  # the first evaluation also builds the device plan
+            state["fac"] = eng.fac
+        elif state["fac"] is None:
+            state["fac"] = sym.factorize(sigma2_of(i))
         else:
             state["fac"].refactorize(sigma2_of(i))
         fac = state["fac"]
         logdets.append(fac.logdet())
-        fac.solve_dev(ctypes.c_void_p(dB.data_ptr()), r, ctypes.c_void_p(dX.data_ptr()))
+        fac.solve_dev(ctypes.c_void_p(dB.data_ptr()), wpad, ctypes.c_void_p(dX.data_ptr()))
         sym.sync()
+        if world > 1:
+            dist.all_gather(gathered, dX)  # every rank ends with all 103 solution columns (as the REML evaluation needs)
 
-    # ---- warm-up: the first evaluation (one-time plan + allocations), then what the budget allows
     t0 = time.time()
     step(0)  # the plan-building evaluation always runs before the timed region: it is the first warm-up step
     t_first = time.time() - t0
@@ -202,24 +239,22 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed, float(info.nnzL), logdets[-1]], dtype=torch.float64, device=rdev)
     if world > 1:
-        tmax = tt.clone()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-        nnzL_total = float(tsum[1])
-        logdet_total = float(tsum[2])
-    else:
-        nnzL_total = float(info.nnzL)
-        logdet_total = logdets[-1]
+    nnzL_total = float(info.nnzL)  # ONE cohort, whatever the number of ranks
+    logdet_total = logdets[-1]
 
     # residual check of the last solve (outside the timed region)
     fac = state["fac"]
-    X = dX[:, :3].cpu().numpy()
+    if world == 1:
+        X = dX[:, :r].cpu().numpy()
+    else:
+        X = np.concatenate([g.cpu().numpy()[:, :b - a] for g, (a, b) in zip(gathered, chunks)], axis=1)
     s2 = sigma2_of(steps - 1)
-    resid = float(np.abs(s2[0] * (A @ X) + s2[1] * X - B_host[:, :3]).max() / np.abs(B_host[:, :3]).max())
+    probe = [0, c, r - 1]  # first covariate column, the phenotype, the last simulated vector (last rank's share)
+    resid = float(np.abs(s2[0] * (A @ X[:, probe]) + s2[1] * X[:, probe] - B_host[:, probe]).max() / np.abs(B_host[:, probe]).max())
 
     if rank == 0:
         K = steps
@@ -249,7 +284,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": warm_done,
             "steps_requested": args.steps, "warmup_requested": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "simulated pedigree %s (n=%d after unrelated-drop, sparsity_factor %g), K=2 (A + I), "
                                    "r=%d fused right-hand sides" % (args.workload, n, WORKLOADS[args.workload][1], r),
@@ -257,7 +292,9 @@ def main():
                        "step_budget": "; ".join(reasons) if reasons else "requested counts run unchanged",
                        "n": n, "nnz_tril_A": int((A.nnz + n) // 2), "nnzL": int(info.nnzL),
                        "nnzL_stored": int(info.nnzL_stored), "factor_flops": info.flops, "nsuper": info.nsuper,
-                       "nlevels": info.nlevels, "per_rank_cohorts": 1,
+                       "nlevels": info.nlevels,
+                       "parallelism": "1 GPU" if world == 1 else "one cohort over %d ranks: separator chain 1-D block-cyclic "
+                                      "with panel broadcast (RCCL), prelude replicated, solve columns split" % world,
                        "seconds_per_step": elapsed / K,
                        "factorize_ms": prof["factor_ms"] / K, "assemble_ms": prof["assemble_ms"] / K,
                        "solve_ms": (prof["solve_fwd_ms"] + prof["solve_bwd_ms"]) / K,

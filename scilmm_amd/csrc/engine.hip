@@ -1021,6 +1021,26 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           D->red_split[l] = (int64_t)red_tiles.size() - D->red_ptr[l];
         }
       }
+      // Launch order = K-segment major, tile minor: the workgroups resident at any moment then work on the SAME few
+      // descendant panels (their target-column rows -- the B operand -- are shared by every tile of the level), so that
+      // operand comes out of the L2s / the infinity cache instead of HBM once per tile.  (Slots were assigned above:
+      // the partial slabs of a tile stay contiguous whatever the launch order.)
+      if (!D->split_lv[l]) {
+        auto seg_major = [&](std::vector<UpdWork>& v, size_t first) {
+          if (v.size() - first < 2) return;
+          std::vector<std::pair<int32_t, int32_t>> key(v.size() - first);  // (segment index within its tile, position)
+          int32_t seg = 0;
+          for (size_t k = first; k < v.size(); ++k) {
+            seg = (k > first && v[k].tile == v[k - 1].tile) ? seg + 1 : 0;
+            key[k - first] = {seg, (int32_t)(k - first)};
+          }
+          std::stable_sort(key.begin(), key.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+          std::vector<UpdWork> tmp(v.begin() + first, v.end());
+          for (size_t k = 0; k < key.size(); ++k) v[first + k] = tmp[(size_t)key[k].second];
+        };
+        seg_major(work_early, (size_t)D->early_ptr[l]);
+        seg_major(work, (size_t)D->work_ptr[l]);
+      }
       max_slots = std::max(max_slots, slots);
       D->lev_cost_e.push_back(total_e);
       D->lev_cost_l.push_back(total_l);
@@ -1286,6 +1306,8 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_update3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1415,6 +1437,14 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       return;
     }
 #endif
+    if (D->update_variant == 3) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL((k_update3<true>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+      else
+        hipLaunchKernelGGL((k_update3<false>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+      launches++;
+      return;
+    }
     if (D->use_mfma && D->update_variant == 2)
       hipLaunchKernelGGL((k_update2<true>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     else if (D->use_mfma)

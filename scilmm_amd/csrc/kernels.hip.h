@@ -645,6 +645,241 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update2(DevSy
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_update3: k_update2 with the matrix pipe driven by v_mfma_f64_4x4x4f64 (four independent 4x4x4 blocks per
+// instruction) instead of v_mfma_f64_16x16x4_f64.  Measured on this GPU (csrc/tools/mfma_sweep.hip,
+// profiles/r2_mfma_sweep.txt): the 16x16x4 form issues every ~105 cycles per SIMD (49 TFLOP/s chip-wide, whatever the
+// number of busy CUs), the 4x4x4 form every ~17 cycles for a quarter of the flops = 75 TFLOP/s, 95 % of the
+// 78.6 TFLOP/s datasheet figure.  The price is operand bandwidth (64 + 64 operand values per 256 MACs instead of
+// per 1024), paid from registers: per k-step a wave reads its 4 row operands (rows replicated over the 4 blocks:
+// an LDS broadcast) and 8 column operands once and issues 8 x 4 MFMAs on them -- 12 LDS reads per 32 MFMAs.
+// Lane roles of the instruction as probed on gfx950 (csrc/tools/mfma_probe.hip, profiles/r2_mfma_probe.txt):
+//   A operand: lane = 16 k + 4 block + i      B operand: lane = 16 k + 4 block + j      D: lane = 16 i + 4 block + j
+// Used here with the COLUMN operand as A, replicated over the blocks (4 target columns x 4 k), and the ROW operand
+// as B (rows 4 block + j: 16 tile rows x 4 k), so one instruction updates a 16-row x 4-column piece of the tile and
+// result lane l holds row (l & 15), column (l >> 4) of it: 16 consecutive lanes = 16 consecutive rows of one panel
+// column (128 contiguous bytes in the epilogue, like the 16x16x4 form).  Wave wv owns target columns
+// [16 wv, 16 wv + 16) x all 128 rows as 8 x 4 such pieces.
+template <bool MFMA>
+__global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update3(DevSym S, const UpdWork* __restrict__ work,
+                                                 const ComboDesc* __restrict__ combos, double* __restrict__ L,
+                                                 double* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Abuf = smem;                         // [2][KC*LDA]
+  double* Bbuf = smem + 2 * KC * LDA;          // [2][KC*LDB]
+  int32_t* rowlab = (int32_t*)(smem + 2 * KC * LDA + 2 * KC * LDB);  // [TM]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const UpdWork wk = work[blockIdx.x];
+  const int32_t g = wk.tile;
+  const int64_t cb = wk.cb, ce = wk.ce;
+  if (cb >= ce) return;
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  const int ncb = (w + 15) >> 4;
+  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
+  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
+  // acc4[p][q]: this lane's element of the piece (rows 16 p .., columns 16 wv + 4 q ..): one double per MFMA
+  constexpr int NRB = TM / 16;
+  double acc4[NRB][4];
+#pragma unroll
+  for (int a = 0; a < NRB; ++a)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) acc4[a][q4] = 0.0;
+  const int l15 = lane & 15, l3 = lane & 3, lk4 = lane >> 4;
+  constexpr int KA = UPD_THREADS / TM, KB = UPD_THREADS / NB;
+  constexpr int NPA = KC / KA, NPB = KC / KB, NS = KC / 4;  // pieces of A / B per thread, k-steps per chunk
+  static_assert(NPA <= NS && NPB <= NS, "staging pieces must fit the k-steps of a chunk");
+  const int t = tid % TM, kpa = tid / TM;
+  const int q = tid % NB, kpb = tid / NB;
+  // ---- three pipeline stages: L = being loaded into registers, W = being written to LDS, C = being multiplied
+  struct Stage {
+    int ip, jp, kc;              // this thread's tile row / target column (-1: none) and the chunk depth
+    int la, lb;                  // LDS cell offsets: the row / column, or this thread's private pad cell
+    int ip0, nt, jp0, nq;        // uniform mapping (for the same-cells test)
+    int ilo, ihi, jb0, jb1;      // spans (for MFMA skipping)
+    bool valid;
+  };
+  Stage SL{}, SW{}, SC{};
+  int64_t cn = cb;  // cursor of the load stage
+  int k0n = 0;
+  ComboDesc dn = combos[cn];
+  ComboDesc dnext = combos[min(cn + 1, ce - 1)];
+  const double* gpa = nullptr;  // this thread's global read pointers for the load-stage chunk
+  const double* gpb = nullptr;
+  int64_t gmd = 0;
+  auto locate_L = [&]() {
+    SL.valid = true;
+    SL.ip = -1;
+    SL.jp = -1;
+    if (t < dn.nt) {
+      if (dn.ip0 >= 0) {
+        SL.ip = dn.ip0 + t;
+      } else {
+        const int32_t lab = S.sn_rows[dn.rowoff + dn.ta + t];
+        int lo = 0, hi = nrow;
+        while (lo < hi) {
+          int mid = (lo + hi) >> 1;
+          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
+        }
+        SL.ip = lo;
+      }
+    }
+    if (q < dn.nq) SL.jp = (dn.jp0 >= 0) ? dn.jp0 + q : S.sn_rows[dn.rowoff + dn.p0 + q] - c0;
+    SL.la = SL.ip >= 0 ? SL.ip : TM + (t & 15);
+    SL.lb = SL.jp >= 0 ? SL.jp : NB + (q & 15);
+    SL.ip0 = dn.ip0; SL.nt = dn.nt; SL.jp0 = dn.jp0; SL.nq = dn.nq;
+    SL.ilo = dn.ilo; SL.ihi = dn.ihi; SL.jb0 = dn.jlo >> 4; SL.jb1 = min(dn.jhi >> 4, ncb - 1);
+  };
+  auto point_L = [&]() {
+    SL.kc = min(KC, dn.wd - k0n);
+    gmd = dn.md;
+    const double* Pd = L + dn.loff + (int64_t)k0n * gmd;
+    // threads without a row / column of this combo read a valid neighbour's element (the value is never used:
+    // it lands in that thread's private LDS pad cell), so the hot loop needs no per-thread predicate
+    gpa = Pd + dn.ta + (SL.ip >= 0 ? t : 0);
+    gpb = Pd + dn.p0 + (SL.jp >= 0 ? q : 0);
+  };
+  auto advance_L = [&]() {
+    // move the load cursor to the next chunk; invalidates SL at the end of the work item
+    k0n += KC;
+    if (k0n >= dn.wd) {
+      ++cn;
+      k0n = 0;
+      if (cn >= ce) { SL.valid = false; return; }
+      dn = dnext;
+      dnext = combos[min(cn + 1, ce - 1)];
+      locate_L();
+    }
+    point_L();
+  };
+  double ra[NPA], rb[NPB];
+  // branch-free pieces: k is clamped into the chunk for the load, and rows beyond the chunk depth are written as
+  // zeros (so every cell a thread owns in a buffer is rewritten by every chunk: no stale k rows)
+  auto load_piece = [&](int i) {
+    if (i < NPA) ra[i] = gpa[(int64_t)min(kpa + KA * i, SL.kc - 1) * gmd];
+    if (i < NPB) rb[i] = gpb[(int64_t)min(kpb + KB * i, SL.kc - 1) * gmd];
+  };
+  auto write_piece = [&](int i, double* As, double* Bs) {
+    if (i < NPA) As[(kpa + KA * i) * LDA + SW.la] = (kpa + KA * i < SW.kc) ? ra[i] : 0.0;
+    if (i < NPB) Bs[(kpb + KB * i) * LDB + SW.lb] = (kpb + KB * i < SW.kc) ? rb[i] : 0.0;
+  };
+  // what each LDS buffer currently holds (per-thread cells + uniform mapping)
+  int h_ip[2] = {-1, -1}, h_jp[2] = {-1, -1}, h_kc[2] = {0, 0};
+  int u_ip0[2] = {-2, -2}, u_nt[2] = {0, 0}, u_jp0[2] = {-2, -2}, u_nq[2] = {0, 0};
+  auto same_cells = [&](int b) -> bool {
+    return SW.ip0 >= 0 && SW.ip0 == u_ip0[b] && SW.nt == u_nt[b] && SW.jp0 >= 0 && SW.jp0 == u_jp0[b] && SW.nq == u_nq[b];
+  };
+  auto clear_own = [&](int b) {
+    double* As = Abuf + b * KC * LDA;
+    double* Bs = Bbuf + b * KC * LDB;
+    if (h_ip[b] >= 0) {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) As[(kpa + KA * i) * LDA + h_ip[b]] = 0.0;
+    }
+    if (h_jp[b] >= 0) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) Bs[(kpb + KB * i) * LDB + h_jp[b]] = 0.0;
+    }
+  };
+  auto record = [&](int b) {
+    h_ip[b] = SW.ip; h_jp[b] = SW.jp; h_kc[b] = SW.kc;
+    u_ip0[b] = SW.ip0; u_nt[b] = SW.nt; u_jp0[b] = SW.jp0; u_nq[b] = SW.nq;
+  };
+  __syncthreads();  // rowlab + zeroed buffers visible
+  // ---- prologue: chunk 0 -> registers -> buffer 0; chunk 1 -> registers
+  locate_L();
+  point_L();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) load_piece(i);
+  SW = SL;
+  advance_L();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) write_piece(i, Abuf, Bbuf);
+  record(0);
+  if (SL.valid) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) load_piece(i);
+  }
+  SC = SW;
+  SW = SL;
+  if (SL.valid) advance_L();
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    double* Aw = Abuf + (buf ^ 1) * KC * LDA;
+    double* Bw = Bbuf + (buf ^ 1) * KC * LDB;
+    if (SW.valid && !same_cells(buf ^ 1)) {
+      clear_own(buf ^ 1);
+      __syncthreads();
+    }
+    const double* Ac = Abuf + buf * KC * LDA;
+    const double* Bc = Bbuf + buf * KC * LDB;
+    const int kc4 = (SC.kc + 3) & ~3;
+    const bool mine = wv >= SC.jb0 && wv <= SC.jb1;     // this wave's 16 columns lie inside the chunk's column span
+    const int plo = SC.ilo >> 4, phi = SC.ihi >> 4;     // 16-row groups inside its row span
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (SW.valid) write_piece(i, Aw, Bw);
+      if (SL.valid) load_piece(i);
+      if (mine && 4 * i < kc4) {
+        if (MFMA) {
+          double cv[4];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) cv[q4] = Bc[(4 * i + lk4) * LDB + 16 * wv + 4 * q4 + l3];
+#pragma unroll
+          for (int pr = 0; pr < NRB; ++pr)
+            if (pr >= plo && pr <= phi) {
+              const double rv = Ac[(4 * i + lk4) * LDA + 16 * pr + l15];
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[q4], rv, acc4[pr][q4], 0, 0, 0);
+            }
+        } else {
+          for (int k = 4 * i; k < 4 * i + 4; ++k)
+#pragma unroll
+            for (int pr = 0; pr < NRB; ++pr)
+              if (pr >= plo && pr <= phi)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] += Bc[k * LDB + 16 * wv + 4 * q4 + lk4] * Ac[k * LDA + 16 * pr + l15];
+        }
+      }
+    }
+    if (!SW.valid) break;
+    record(buf ^ 1);
+    SC = SW;
+    SW = SL;
+    if (SL.valid) advance_L();
+    __syncthreads();
+    buf ^= 1;
+  }
+  // epilogue: piece (p, q), lane l -> tile row 16 p + (l & 15), target column 16 wv + 4 q + (l >> 4)
+  if (wk.slot < 0) {
+    double* P = L + S.sn_loff[s];
+#pragma unroll
+    for (int pr = 0; pr < NRB; ++pr)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int j = 16 * wv + 4 * q4 + lk4;
+        const int i = 16 * pr + l15;
+        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc4[pr][q4];
+      }
+  } else {
+    double* Q = scratch + (int64_t)wk.slot * (TM * NB);
+#pragma unroll
+    for (int pr = 0; pr < NRB; ++pr)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int j = 16 * wv + 4 * q4 + lk4;
+        const int i = 16 * pr + l15;
+        Q[j * TM + i] = acc4[pr][q4];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Compact path of the supernodal update: combos whose rows / columns are scattered over the target tile
 // (a family subtree updating a few dozen of the 128 x 128 cells' rows and columns) would keep all eight
 // waves and all column blocks of k_update busy although only ceil(nt/16) x ceil(nq/16) blocks carry data.

@@ -183,7 +183,8 @@ def test_factorization_is_bitwise_reproducible():
 
 
 @pytest.mark.parametrize("env", [{"SCILMM_NO_LOOKAHEAD": "1"}, {"SCILMM_LOOK_DEPTH": "1"}, {"SCILMM_LOOK_DEPTH": "3"},
-                                 {"SCILMM_NO_CHAIN": "1"}, {"SCILMM_UPDATE_VARIANT": "1"}, {"SCILMM_CELL_LIMIT": "64"},
+                                 {"SCILMM_NO_CHAIN": "1"}, {"SCILMM_UPDATE_VARIANT": "1"}, {"SCILMM_UPDATE_VARIANT": "2"},
+                                 {"SCILMM_UPDATE_VARIANT": "3"}, {"SCILMM_UPDATE_VARIANT": "3", "SCILMM_NO_MFMA": "1"}, {"SCILMM_CELL_LIMIT": "64"},
                                  {"SCILMM_HOST_CELLS": "1"}, {"SCILMM_CELL_LIMIT": "100000"}, {"SCILMM_PUSH_SLICE": "256"},
                                  {"SCILMM_CHAIN_WIDE": "1000", "SCILMM_CHAIN_CAP": "100000"}])
 def test_alternative_schedules_agree_with_oracle(monkeypatch, env):

@@ -1,7 +1,8 @@
 """Multi-rank path of the HIP engine, rehearsed on ONE GPU: two processes share the card and exchange the chain
 panels through torch.distributed/gloo (RCCL refuses two ranks on one device; the engine only sees a callback, so
 the code path -- ownership filter of the plan, event ordering around the broadcasts, replicated factor, column-split
-solves -- is the one that runs with backend "nccl" on a multi-GPU node)."""
+solves -- is the one that runs with backend "nccl" on a multi-GPU node).  The file name sorts last on purpose: a
+failure here must not take the single-GPU parity tests with it."""
 import os
 import socket
 
@@ -32,6 +33,8 @@ def _problem():
 
 
 def _worker(rank, world, port, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)  # a stuck collective must not leave a process on the GPU
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
