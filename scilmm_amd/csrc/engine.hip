@@ -141,8 +141,8 @@ struct Dev {
 // such switch gives the same factor to rounding (parity-tested); switches that would change RESULTS (the timing
 // ablations) exist only in builds with -DSCILMM_DIAG.  SCILMM_VERBOSE / SCILMM_LEVEL_DUMP only print.
 inline const char* tune_env(const char* name) {
-  static const bool on = [] { const char* t = tune_env("SCILMM_TUNING"); return t && t[0] == '1'; }();
-  return on ? getenv(name) : nullptr;
+  const char* t = getenv("SCILMM_TUNING");  // read on every call: tests switch it on and off inside one process
+  return (t && t[0] == '1') ? getenv(name) : nullptr;
 }
 
 #define HIPCHK(call)                                                                                   \
@@ -1556,7 +1556,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     };
     auto launch_trsm = [&](hipStream_t stream, const int32_t* tiles, int64_t cnt) {
       if (cnt <= 0) return;
-      if (D->use_mfma)
+      if (D->use_mfma && D->update_variant == 3)
+        hipLaunchKernelGGL(k_trsm4, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
+      else if (D->use_mfma)
         hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
       else
         hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);

@@ -1457,6 +1457,97 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_trsm4: k_trsm with the product on v_mfma_f64_4x4x4f64 (see k_update3 for the lane roles and why it is the faster
+// form on gfx950: this launch is one 128 x 128 x 128 product per workgroup at one wave per SIMD, i.e. pure MFMA
+// issue latency -- 2048 instructions of 17 cycles per wave instead of 512 of 140).  Wave wv owns target columns
+// [32 wv, 32 wv + 32) x all 128 rows as 8 x 8 pieces of 16 rows x 4 columns.
+__global__ __launch_bounds__(256) void k_trsm4(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
+                                               const double* __restrict__ invD) {
+  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  if (R0 + nrow <= w) return;  // tile lies entirely inside the diagonal block
+  double* P = L + S.sn_loff[s];
+  const double* I = invD + S.inv_off[s];
+  constexpr int NRB = TM / 16, NQ = 8;
+  double acc4[NRB][NQ];
+#pragma unroll
+  for (int a = 0; a < NRB; ++a)
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) acc4[a][b] = 0.0;
+  constexpr int PA = KCS / 2, PB = KCS / (256 / NB);  // values per thread and chunk: A row t, B column q
+  const int t = tid & 127, ka = tid >> 7;
+  const int q = tid % NB, kb = tid / NB;
+  const bool ha = t < nrow, hb = q < w;
+  const double* pa = P + R0 + (ha ? t : 0);
+  const double* pb = I + (hb ? q : 0);
+  double ra[PA], rb[PB];
+  auto fetch = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ra[i] = pa[(int64_t)(k0 + min(ka + 2 * i, kc - 1)) * m];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = pb[(int64_t)(k0 + min(kb + (256 / NB) * i, kc - 1)) * w];
+  };
+  auto stage = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = ka + 2 * i;
+      if (k < kc4) As[k * LDA + t] = (ha && k < kc) ? ra[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = kb + (256 / NB) * i;
+      if (k < kc4) Bs[k * LDB + q] = (hb && k < kc) ? rb[i] : 0.0;  // invL[j][k] -> Bs[k][j]
+    }
+  };
+  const int l15 = lane & 15, l3 = lane & 3, lk4 = lane >> 4;
+  const int prn = (nrow + 15) >> 4;      // 16-row groups that carry rows
+  const bool wave_on = 32 * wv < w;      // this wave's 32 columns exist
+  fetch(0);
+  for (int32_t k0 = 0; k0 < w; k0 += KCS) {
+    const int kc = min(KCS, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (k0 > 0) __syncthreads();  // the previous chunk has been consumed
+    stage(k0);
+    if (k0 + KCS < w) fetch(k0 + KCS);
+    __syncthreads();
+    if (wave_on) {
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        double cv[NQ];
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) cv[q4] = Bs[(k4 + lk4) * LDB + 32 * wv + 4 * q4 + l3];
+#pragma unroll
+        for (int pr = 0; pr < NRB; ++pr)
+          if (pr < prn) {
+            const double rv = As[(k4 + lk4) * LDA + 16 * pr + l15];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4) acc4[pr][q4] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[q4], rv, acc4[pr][q4], 0, 0, 0);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int pr = 0; pr < NRB; ++pr)
+#pragma unroll
+    for (int q4 = 0; q4 < NQ; ++q4) {
+      const int j = 32 * wv + 4 * q4 + lk4;
+      const int i = 16 * pr + l15;
+      if (i < nrow && R0 + i >= w && j < w) P[(int64_t)j * m + R0 + i] = acc4[pr][q4];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Right-hand-side kernels.  rp = padded column count (multiple of 16, <= RPMAX); ldy = LDS leading
 // dimension of [k][c] images (== 16 mod 32 so that b64 reads of Bop[k][c] are conflict-free).
 
