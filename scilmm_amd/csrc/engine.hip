@@ -161,8 +161,13 @@ struct DevGuard {
   bool switched = false;
   explicit DevGuard(const scilmm_symbolic* sym) {
     const Dev* D = sym ? (const Dev*)sym->device : nullptr;
-    if (!D) return;
-    if (hipGetDevice(&prev) == hipSuccess && prev != D->device) switched = hipSetDevice(D->device) == hipSuccess;
+    if (D) enter(D->device);
+  }
+  explicit DevGuard(int device) { enter(device); }
+  void enter(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    if (!switched) (void)hipGetLastError();  // never leave a failed hipSetDevice behind as the thread's "last error"
   }
   ~DevGuard() {
     if (switched) (void)hipSetDevice(prev);
@@ -397,6 +402,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     sym->err = "no HIP device available (the numeric phase has no CPU fallback)";
     return SCILMM_ERR_DEVICE;
+  }
+  {
+    // a stale "last error" of this host thread (left by any earlier runtime call, ours or the caller's) would be
+    // reported by the first library that polls hipGetLastError() -- hipCUB does, inside the plan construction
+    const hipError_t stale = hipGetLastError();
+    if (stale != hipSuccess && getenv("SCILMM_VERBOSE"))
+      fprintf(stderr, "[scilmm plan] cleared a stale HIP error of this thread: %s\n", hipGetErrorString(stale));
   }
   Dev* D = new Dev();
   sym->device = D;
@@ -1350,6 +1362,7 @@ struct scilmm_factor {
   double* logd = nullptr;
   int32_t* status = nullptr;
   bool valid = false;
+  int device = -1;            // device of the owning handle (kept here: the factor may outlive its symbolic handle's Dev)
   bool external = false;      // L / invD / logd belong to the caller (scilmm_factor_create_external)
   bool pending = false;       // a factorization has been queued (scilmm_refactorize_async) and not yet waited for
   int32_t* h_status = nullptr;  // pinned host copy of *status, filled by the queued copy
@@ -2049,6 +2062,7 @@ static int factor_create(scilmm_symbolic* sym, double* L_ext, double* invD_ext, 
   const Symbolic& S = *sym->S;
   scilmm_factor* f = new scilmm_factor();
   f->sym = sym;
+  f->device = D->device;
   *out = f;
   size_t nL, padL, nI, padI;
   factor_sizes(S, &nL, &padL, &nI, &padI);
@@ -2120,7 +2134,7 @@ int scilmm_factor_wait(scilmm_factor* fac, int32_t* bad_col) {
 
 void scilmm_factor_free(scilmm_factor* fac) {
   if (!fac) return;
-  DevGuard guard(fac->sym);
+  DevGuard guard(fac->device);
   if (fac->pending) (void)finish_factorize(fac, nullptr);
   if (fac->h_status) (void)hipHostFree(fac->h_status);
   if (!fac->external) {
