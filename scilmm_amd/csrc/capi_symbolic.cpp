@@ -67,6 +67,11 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
   if (!h || !h->S || !what || !count) return SCILMM_ERR_ARG;
   if (!h->S->combos_built && !std::strncmp(what, "combo_", 6)) scilmm::build_tile_combos(h->S, nullptr);
   const Symbolic& S = *h->S;
+  if (!std::strcmp(what, "dense_first")) {
+    if (out) *(int32_t*)out = S.dense_first;
+    *count = 1;
+    return SCILMM_OK;
+  }
   GET("perm", perm)
   GET("iperm", iperm)
   GET("parent", parent)

@@ -477,6 +477,14 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   }
   S->nlevels = 0;
   for (int32_t s = 0; s < ns; ++s) S->nlevels = std::max(S->nlevels, S->sn_level[s] + 1);
+  // dense tail: the maximal suffix of fronts whose row list is "every column from my first one on" (such a front
+  // cannot be followed by a column that is not its ancestor, so the suffix is a chain with consecutive indices)
+  S->dense_first = ns;
+  while (S->dense_first > 0) {
+    const int32_t q = S->dense_first - 1;
+    if (S->sn_rowptr[q + 1] - S->sn_rowptr[q] != (int64_t)n - out[q].start) break;
+    S->dense_first = q;
+  }
 
   // children lists (increasing order)
   S->child_ptr.assign(ns + 1, 0);
@@ -682,7 +690,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 // Step 11b, on demand: for every 128-row tile of every target panel the list of descendant row ranges ("combos")
 // that land in it.  keep_front (optional, [nsuper]) restricts the enumeration to the targets a rank owns in a
 // multi-GPU run; the lists of the other tiles stay empty.
-void build_tile_combos(Symbolic* S, const uint8_t* keep_front) {
+void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense) {
   const int32_t ns = S->nsuper;
   const int32_t TM = S->tile_rows;
   const int64_t nt = S->tile_base[ns];
@@ -707,6 +715,7 @@ void build_tile_combos(Symbolic* S, const uint8_t* keep_front) {
         int64_t ms = S->sn_rowptr[s + 1] - S->sn_rowptr[s];
         for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) {
           int32_t d = S->upd_src[e];
+          if (skip_dense && s >= S->dense_first && d >= S->dense_first) continue;
           const int32_t* rd = S->sn_rows.data() + S->sn_rowptr[d];
           int32_t md = (int32_t)(S->sn_rowptr[d + 1] - S->sn_rowptr[d]);
           int32_t t = S->upd_p0[e];

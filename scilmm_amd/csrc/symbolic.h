@@ -58,6 +58,10 @@ struct Symbolic {
   std::vector<int32_t> sn_rows;   // row lists (sorted; permuted labels)
   std::vector<int64_t> sn_loff;   // [nsuper+1] offsets of the panels in L storage (doubles)
   std::vector<int32_t> sn_level;  // [nsuper] height above the leaves
+  // Fronts [dense_first, nsuper) are the DENSE TAIL: each of them has every later column as a row (m_s = n - start_s),
+  // i.e. together they are one dense lower-triangular matrix cut into block columns (the trailing clique of a
+  // pedigree factor: 16.6k wide at the 100k config, 170k at 1M).  Updates among them need no index lists.
+  int32_t dense_first = 0;
   // children lists
   std::vector<int64_t> child_ptr; // [nsuper+1]
   std::vector<int32_t> child_idx; // children of each front in increasing order
@@ -114,6 +118,8 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 
 // Fills Symbolic::combo_* (step 11b of the analysis).  keep_front: optional [nsuper] mask of the target fronts whose
 // tiles are enumerated (multi-GPU: the targets this rank owns); NULL = all.
-void build_tile_combos(Symbolic* S, const uint8_t* keep_front);
+// skip_dense: leave out the update pairs whose target AND descendant lie in the dense tail (the engine handles those
+// with implicit, descriptor-free work items).
+void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense = false);
 
 }  // namespace scilmm
