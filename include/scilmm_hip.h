@@ -46,6 +46,8 @@ typedef struct scilmm_options {
   int32_t max_width;    /* split supernodes wider than this (0 = library default) */
   double nd_oksep;      /* nested dissection: accept a separator only below this share of its subgraph (0 = default 0.1;
                            1.0 = always dissect, CHOLMOD's nd_oksep default) */
+  double dense_relax;   /* the trailing chain of fronts is padded to a dense block-column matrix while padded / true
+                           flops stay below this (0 = default 1.10; negative = never pad) */
 } scilmm_options;
 
 typedef struct scilmm_info {
@@ -56,8 +58,10 @@ typedef struct scilmm_info {
   double flops;         /* sum_j colcount_j^2 (CHOLMOD "fl" convention) */
   int64_t n_rows_total; /* sum_s m_s */
   int64_t n_updates;    /* number of (target, descendant) update pairs */
-  double update_flops;  /* algorithmic flops of the supernodal update kernel (lower-triangular count) */
+  double update_flops;  /* algorithmic flops of the supernodal update kernels (lower-triangular count, true structure) */
   double solve_flops_per_rhs; /* 4 nnz(L_stored) : forward + backward sweep per right-hand side */
+  double update_flops_executed; /* update_flops plus the explicit zeros of the padded dense tail */
+  int32_t dense_first;  /* fronts [dense_first, nsuper) form the dense tail (nsuper: none) */
 } scilmm_info;
 
 /* --- symbolic phase: replaces cholmod_analyze inside sk_cholesky (SparseCholesky.py:23-26), but once per

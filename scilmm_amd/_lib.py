@@ -30,11 +30,11 @@ class Options(C.Structure):
     _fields_ = [("ordering", C.c_int32), ("relax_small", C.c_int32), ("relax_w1", C.c_int32),
                 ("relax_w2", C.c_int32), ("relax_z1", C.c_double), ("relax_z2", C.c_double),
                 ("relax_z3", C.c_double), ("amd_dense", C.c_double), ("max_width", C.c_int32),
-                ("nd_oksep", C.c_double)]
+                ("nd_oksep", C.c_double), ("dense_relax", C.c_double)]
 
     @classmethod
     def default(cls, ordering=0, **kw):
-        o = cls(ordering, -1, -1, -1, -1.0, -1.0, -1.0, 0.0, 0, 0.0)
+        o = cls(ordering, -1, -1, -1, -1.0, -1.0, -1.0, 0.0, 0, 0.0, 0.0)
         for k, v in kw.items():
             setattr(o, k, v)
         return o
@@ -44,7 +44,8 @@ class Info(C.Structure):
     _fields_ = [("n", C.c_int32), ("K", C.c_int32), ("nsuper", C.c_int32), ("nlevels", C.c_int32),
                 ("nnzL", C.c_int64), ("nnzL_stored", C.c_int64), ("nnz_pattern", C.c_int64),
                 ("flops", C.c_double), ("n_rows_total", C.c_int64), ("n_updates", C.c_int64),
-                ("update_flops", C.c_double), ("solve_flops_per_rhs", C.c_double)]
+                ("update_flops", C.c_double), ("solve_flops_per_rhs", C.c_double),
+                ("update_flops_executed", C.c_double), ("dense_first", C.c_int32)]
 
 
 class Timing(C.Structure):

@@ -26,6 +26,7 @@ int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, c
     if (opts->amd_dense != 0) o.amd_dense = opts->amd_dense;
     if (opts->max_width != 0) o.max_width = opts->max_width < 0 ? 0 : opts->max_width;
     if (opts->nd_oksep > 0) o.nd_oksep = opts->nd_oksep;
+    if (opts->dense_relax != 0) o.dense_relax = opts->dense_relax < 0 ? 0.0 : opts->dense_relax;
   }
   if (perm_in && !opts) o.ordering = 2;
   scilmm_symbolic* h = new scilmm_symbolic();
@@ -51,7 +52,9 @@ int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
   info->flops = S.flops;
   info->n_rows_total = (int64_t)S.sn_rows.size();
   info->n_updates = (int64_t)S.upd_src.size();
-  info->update_flops = S.update_flops;
+  info->update_flops = S.update_flops - S.update_flops_pad;  // algorithmic: without the dense-tail padding
+  info->update_flops_executed = S.update_flops;
+  info->dense_first = S.dense_first;
   info->solve_flops_per_rhs = 4.0 * (double)S.nnzL_stored;
   return SCILMM_OK;
 }

@@ -110,6 +110,12 @@ struct Dev {
   std::vector<uint8_t> own_level;       // [nlevels] this rank runs the kernels of level l
   hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
   std::vector<hipEvent_t> done_ev;      // per level: kernels of an owned chain level finished (main stream)
+  // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
+  bool dense_on = false;
+  int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
+  DenseWork* d_dwork_e = nullptr;
+  DenseWork* d_dwork_l = nullptr;
+  std::vector<int64_t> dwork_e_ptr, dwork_l_ptr;  // [nlevels+1]
   int look_depth = 2;      // "late" = descendants at most this many levels below the target; older ones are "early"
   int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
@@ -506,9 +512,18 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       fprintf(stderr, "[scilmm plan] rank %d of %d: distributed chain = levels %d..%d (%d panels, every %d-th one mine)\n", D->rank,
               D->world, l0, S.nlevels - 1, S.nlevels - l0, D->world);
   }
+  {
+    const char* edn = tune_env("SCILMM_DENSE");
+    D->dense_on = S.dense_first < S.nsuper && !(edn && edn[0] == '0');
+    const char* emf = tune_env("SCILMM_DENSE_MF");
+    if (emf) D->dense_mf = atoi(emf) == 4 ? 4 : 16;
+  }
   if (!sym->S->combos_built) {
-    scilmm::build_tile_combos(sym->S, D->world > 1 ? D->keep_front.data() : nullptr);
+    // (a handle analysed through scilmm_symbolic_get("combo_*") carries the full lists: then the dense path stays off)
+    scilmm::build_tile_combos(sym->S, D->world > 1 ? D->keep_front.data() : nullptr, D->dense_on);
     plap("tile combos");
+  } else {
+    D->dense_on = false;
   }
   D->v.n = S.n;
   D->v.nsuper = S.nsuper;
@@ -592,7 +607,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       // under the saturating early updates both run ~1.6x slower than isolated.
       const char* ens = tune_env("SCILMM_SPLIT_CHAIN");
       const char* ecp = tune_env("SCILMM_COMPACT");
-      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1') && D->world == 1;
+      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1') && D->world == 1 && !D->dense_on;
       int64_t why[3] = {0, 0, 0};
       for (int32_t l = 1; allow && l + 1 < S.nlevels; ++l) {
         if (S.level_ptr[l + 1] - S.level_ptr[l] != 1 || S.level_ptr[l + 2] - S.level_ptr[l + 1] != 1) continue;
@@ -914,6 +929,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<int32_t> pslot_e(pslot.size(), 0), pnseg_e(pslot.size(), 0), red_tiles_e;
     D->red_ptr_e.assign(S.nlevels + 1, 0);
     std::vector<UpdWork> work, work_early, cwork, cwork_early;
+    std::vector<DenseWork> dwork_e, dwork_l;
+    D->dwork_e_ptr.assign(S.nlevels + 1, 0);
+    D->dwork_l_ptr.assign(S.nlevels + 1, 0);
     D->work_split.assign(std::max(S.nlevels, 1), 0);
     D->red_split.assign(std::max(S.nlevels, 1), 0);
     D->cwork_ptr.assign(S.nlevels + 1, 0);
@@ -965,12 +983,43 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         for (int64_t c = dptr[g]; c < dmid[g]; ++c) total_e += combo_cost_d(c);
         for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost_d(c);
       }
+      // dense tail: the level's (single) front j = dense_first + jj receives every earlier tail front; the last
+      // look_depth of them are "late", the others "early" -- implicit items, one per (pair of tiles, K segment)
+      int32_t dj = -1, dcnt_e = 0, dcnt_l = 0;
+      const int64_t dunit = 1 + (NB + KC - 1) / KC;  // cost units of one tail descendant on one tile
+      int32_t dfr = -1;  // the tail fronts lie on a chain: at most one of them per level
+      if (D->dense_on)
+        for (int32_t q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q)
+          if (S.level_fronts[q] >= S.dense_first) dfr = S.level_fronts[q];
+      if (dfr >= 0) {
+        const int32_t fr = dfr;
+        if (D->keep_front[fr]) {
+          dj = fr;
+          const int32_t jj = fr - S.dense_first;
+          dcnt_l = lookahead ? std::min<int32_t>(depth, jj) : jj;
+          dcnt_e = jj - dcnt_l;
+          const int64_t ntl = S.tile_base[fr + 1] - S.tile_base[fr];
+          total_e += ntl * dunit * dcnt_e;
+          total_l += ntl * dunit * dcnt_l;
+        }
+      }
       const int64_t big = (int64_t)1 << 60;
       // (at most ~8192 items per launch: the slabs of a level must stay a few GB on the largest patterns)
       const int64_t cap_e = std::max<int64_t>(max_item, total_e / 8192), cap_l = std::max<int64_t>(max_item, total_l / 8192);
       const int64_t per_e = allow_split ? std::min(cap_e, std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items)) : big;
       const int64_t per_l = allow_split ? std::min(cap_l, std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items)) : big;
       int64_t slots = 0;
+      // K segments of the dense-tail items (the same for every tile of the front) and, per tile, their first slab
+      auto dense_nseg = [&](int32_t cnt, int64_t per_item) -> int64_t {
+        if (cnt <= 0) return 0;
+        return std::min<int64_t>(std::min<int64_t>(64, cnt), std::max<int64_t>(1, (dunit * cnt + per_item / 2) / per_item));
+      };
+      const int64_t nde = dense_nseg(dcnt_e, per_e), ndl = dense_nseg(dcnt_l, per_l);
+      std::vector<int32_t> dbase_e, dbase_l;  // per tile of front dj: first dense slab, -1 = subtract directly
+      if (dj >= 0) {
+        dbase_e.assign((size_t)(S.tile_base[dj + 1] - S.tile_base[dj]), -1);
+        dbase_l.assign(dbase_e.size(), -1);
+      }
       // a split level lists its diagonal tile first: the late items / reduce entries of that tile lead the level
       std::vector<int32_t> order(S.level_tiles.begin() + S.level_tile_ptr[l], S.level_tiles.begin() + S.level_tile_ptr[l + 1]);
       // heaviest tiles (most combos) first: the long items of a launch start early
@@ -1009,24 +1058,29 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         }
         // a single dense item of a launch subtracts straight into the panel (the early and the late launch of a
         // level never overlap in time); two or more go through partial slabs; slab-mode compact items always do
-        const int64_t pe = ne >= 2 ? ne : 0, pl = nl >= 2 ? nl : 0;
-        if (ne == 1) work_early[fe].slot = -1;
-        if (nl == 1) work[fl].slot = -1;
-        if (pe + nce > 0) {
+        // (the implicit dense-tail items of the tile count like explicit ones: dte / dtl of them)
+        const int64_t dte = (dj >= 0 && S.tile_front[g] == dj) ? nde : 0, dtl = (dj >= 0 && S.tile_front[g] == dj) ? ndl : 0;
+        const int64_t pe = (ne + dte) >= 2 ? ne : 0, pl = (nl + dtl) >= 2 ? nl : 0;
+        const int64_t pde = (ne + dte) >= 2 ? dte : 0, pdl = (nl + dtl) >= 2 ? dtl : 0;
+        if (ne == 1 && pe == 0) work_early[fe].slot = -1;
+        if (nl == 1 && pl == 0) work[fl].slot = -1;
+        if (pe + nce + pde > 0) {
           pslot_e[g] = (int32_t)slots;
-          pnseg_e[g] = (int32_t)(pe + nce);
+          pnseg_e[g] = (int32_t)(pe + nce + pde);
           red_tiles_e.push_back(g);
           for (int64_t k = 0; k < pe; ++k) work_early[fe + k].slot = (int32_t)(slots + k);
           for (int64_t k = 0; k < nce; ++k) cwork_early[cfe + k].slot = (int32_t)(slots + pe + k);
-          slots += pe + nce;
+          if (pde > 0) dbase_e[(size_t)(g - S.tile_base[dj])] = (int32_t)(slots + pe + nce);
+          slots += pe + nce + pde;
         }
-        if (pl + ncl > 0) {
+        if (pl + ncl + pdl > 0) {
           pslot[g] = (int32_t)slots;
-          pnseg[g] = (int32_t)(pl + ncl);
+          pnseg[g] = (int32_t)(pl + ncl + pdl);
           red_tiles.push_back(g);
           for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + k);
           for (int64_t k = 0; k < ncl; ++k) cwork[cfl + k].slot = (int32_t)(slots + pl + k);
-          slots += pl + ncl;
+          if (pdl > 0) dbase_l[(size_t)(g - S.tile_base[dj])] = (int32_t)(slots + pl + ncl);
+          slots += pl + ncl + pdl;
         }
         if (oi == 0) {  // first tile of the level = the diagonal tile of a split level's front
           D->work_split[l] = (int64_t)work.size() - D->work_ptr[l];
@@ -1053,6 +1107,27 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         seg_major(work_early, (size_t)D->early_ptr[l]);
         seg_major(work, (size_t)D->work_ptr[l]);
       }
+      if (dj >= 0) {
+        // K-segment major, tile-pair minor (same reason as above); a pair = two vertically adjacent tiles of the front
+        const int32_t ntl = (int32_t)(S.tile_base[dj + 1] - S.tile_base[dj]);
+        const int32_t jj = dj - S.dense_first;
+        auto emit = [&](std::vector<DenseWork>& out, int64_t nseg, int32_t kfirst, int32_t cnt, const std::vector<int32_t>& base) {
+          for (int64_t sg = 0; sg < nseg; ++sg) {
+            const int32_t k0 = kfirst + (int32_t)((int64_t)cnt * sg / nseg), k1 = kfirst + (int32_t)((int64_t)cnt * (sg + 1) / nseg);
+            if (k1 <= k0) continue;
+            for (int32_t q = 0; q < ntl; q += 2) {
+              const int32_t nt2 = std::min<int32_t>(2, ntl - q);
+              DenseWork wk{dj, q, nt2, k0, k1, base[(size_t)q] < 0 ? -1 : base[(size_t)q] + (int32_t)sg,
+                           (nt2 == 2 && base[(size_t)q + 1] >= 0) ? base[(size_t)q + 1] + (int32_t)sg : -1, 0};
+              out.push_back(wk);
+            }
+          }
+        };
+        emit(dwork_e, nde, 0, dcnt_e, dbase_e);
+        emit(dwork_l, ndl, jj - dcnt_l, dcnt_l, dbase_l);
+      }
+      D->dwork_e_ptr[l + 1] = (int64_t)dwork_e.size();
+      D->dwork_l_ptr[l + 1] = (int64_t)dwork_l.size();
       max_slots = std::max(max_slots, slots);
       D->lev_cost_e.push_back(total_e);
       D->lev_cost_l.push_back(total_l);
@@ -1106,6 +1181,19 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->d_cwork = (UpdWork*)dcw;
       if ((st = upload(sym, D, cwork_early, &dcw)) != SCILMM_OK) return st;
       D->d_cwork_early = (UpdWork*)dcw;
+    }
+    {
+      if (dwork_e.empty()) dwork_e.push_back(DenseWork{});
+      if (dwork_l.empty()) dwork_l.push_back(DenseWork{});
+      const DenseWork* ddw;
+      if ((st = upload(sym, D, dwork_e, &ddw)) != SCILMM_OK) return st;
+      D->d_dwork_e = (DenseWork*)ddw;
+      if ((st = upload(sym, D, dwork_l, &ddw)) != SCILMM_OK) return st;
+      D->d_dwork_l = (DenseWork*)ddw;
+      if (getenv("SCILMM_VERBOSE"))
+        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d)\n",
+                S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,
+                (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels], D->dense_mf);
     }
     if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
     {
@@ -1318,6 +1406,9 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1468,6 +1559,17 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       hipLaunchKernelGGL((k_update<false, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
     launches++;
   };
+  const size_t sm_dense = sizeof(double) * (size_t)(2 * KC * LDA2 + 2 * KC * LDB);
+  auto launch_dense = [&](hipStream_t stream, const DenseWork* dw, int64_t cnt, double* scratch_half) {
+    if (cnt <= 0) return;
+    if (!D->use_mfma)
+      hipLaunchKernelGGL((k_dense<4, false>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
+    else if (D->dense_mf == 4)
+      hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
+    else
+      hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
+    launches++;
+  };
   const size_t half = (size_t)D->max_slots * TM * NB;
   auto launch_compact = [&](hipStream_t stream, const UpdWork* cw, int64_t cnt, double* slabs = nullptr) {
     if (cnt <= 0) return;
@@ -1489,7 +1591,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     launches++;
   };
   auto has_early = [&](int32_t l) -> bool {
-    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cearly_ptr[l + 1] > D->cearly_ptr[l] || D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l];
+    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cearly_ptr[l + 1] > D->cearly_ptr[l] ||
+           D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l] || D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l];
   };
   // Look-ahead: the EARLY part of level l+1 (descendants finished at levels <= l-1) runs on the side stream
   // while the main stream works through level l's latency-bound tail (late update, reduce, cells, potrf, trsm).
@@ -1514,6 +1617,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
+    launch_dense(sd, D->d_dwork_e + D->dwork_e_ptr[l], D->dwork_e_ptr[l + 1] - D->dwork_e_ptr[l], D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
     if (slab_compact) HIPCHK(hipStreamWaitEvent(sd, D->chain_ev[3 * l], 0));
     {
@@ -1591,6 +1695,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         }
         if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
         if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+        launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], D->dwork_l_ptr[l + 1] - D->dwork_l_ptr[l], sh);
         if (D->compact_mode == 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l], sh);
         if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
         launch_reduce(st, r0, r1);
@@ -1708,15 +1813,15 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
     int64_t nu = 0;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       float x = 0;
-      if (D->work_ptr[l + 1] > D->work_ptr[l]) {
+      if (D->work_ptr[l + 1] > D->work_ptr[l] || D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]) {
         HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 0], D->pev[PE * l + 1]));
         tu += x;
-        nu++;
+        nu += (D->work_ptr[l + 1] > D->work_ptr[l]) + (D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]);
       }
-      if (D->early_ptr[l + 1] > D->early_ptr[l]) {
+      if (D->early_ptr[l + 1] > D->early_ptr[l] || D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
         HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 5], D->pev[PE * l + 6]));
         tu += x;
-        nu++;
+        nu += (D->early_ptr[l + 1] > D->early_ptr[l]) + (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]);
       }
       HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 1], D->pev[PE * l + 2]));
       tmid += x;
@@ -1735,12 +1840,12 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
       std::vector<std::pair<float, float>> iv;
       for (int32_t l = 0; l < S.nlevels; ++l) {
         float a0 = 0, a1 = 0;
-        if (D->work_ptr[l + 1] > D->work_ptr[l]) {
+        if (D->work_ptr[l + 1] > D->work_ptr[l] || D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]) {
           HIPCHK(hipEventElapsedTime(&a0, D->ev[1], D->pev[PE * l + 0]));
           HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 1]));
           iv.push_back({a0, a1});
         }
-        if (D->early_ptr[l + 1] > D->early_ptr[l]) {
+        if (D->early_ptr[l + 1] > D->early_ptr[l] || D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
           HIPCHK(hipEventElapsedTime(&a0, D->ev[1], D->pev[PE * l + 5]));
           HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 6]));
           iv.push_back({a0, a1});

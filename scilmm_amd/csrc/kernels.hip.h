@@ -880,6 +880,167 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update3(DevSy
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_dense: update of the DENSE TAIL by the dense tail (Symbolic::dense_first): both the target panel j and the
+// descendant panels k0..k1-1 have every later column as a row, so the operands are plain column-major blocks found
+// by arithmetic -- row r of the target is row (c0_j - c0_d + r) of descendant d -- and the kernel needs no row
+// lists, no combo descriptors, no binary searches, no clearing of LDS cells, no spans.  This is > 99.9 % of the
+// factor flops at the 1M-individual config (170k-wide tail) and 82 % at 100k.
+//   acc[256 x 128] = sum_d  L_d[rows of the two 128-row target tiles, :] * L_d[rows = target columns, :]^T
+// One workgroup = TWO vertically adjacent 128-row target tiles that share the B operand (the descendant rows at the
+// target's columns): 21 flop per staged byte instead of 16, and one workgroup per CU so that the accumulators
+// (64 doubles per lane) and a whole chunk of global loads in flight fit the register file.  The K dimension is
+// streamed in chunks of KC through a double-buffered k-major LDS image; the loads of chunk c+1 are issued before the
+// MFMAs of chunk c and written to the other buffer after them (one barrier per chunk).
+// MF selects the matrix instruction: 16 = v_mfma_f64_16x16x4_f64 (wave = 32 rows x 128 columns), 4 =
+// v_mfma_f64_4x4x4f64 (wave = 16 columns x 256 rows, see k_update3).
+struct DenseWork {
+  int32_t front;       // target front j (>= dense_first)
+  int32_t ti0;         // first of the (one or two) target tiles
+  int32_t ntiles;      // 1 or 2
+  int32_t k0, k1;      // descendants dense_first + k0 .. dense_first + k1 - 1
+  int32_t slot0, slot1;  // partial slab of each tile, or -1: subtract straight from the panel
+  int32_t pad;
+};
+constexpr int DTR = 2 * TM;        // rows per dense work item
+constexpr int LDA2 = DTR + 16;     // == 16 mod 32 doubles: conflict-free b64 fragment reads
+
+template <int MF, bool MFMA>
+__global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                  double* __restrict__ L, double* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Abuf = smem;                      // [2][KC][LDA2]
+  double* Bbuf = smem + 2 * KC * LDA2;      // [2][KC][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;             // dense tail: the rows of front j are the labels c0j .. n-1
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  // staging roles: A row ta with k phase ka (of 2), B column tb with k phase kb (of 4)
+  constexpr int NPA = KC / 2, NPB = KC / 4;
+  const int ta = tid & (DTR - 1), ka = tid >> 8;
+  const int tb = tid & (NB - 1), kb = tid >> 7;
+  const int ra_row = min(ta, nrow - 1), rb_col = min(tb, wj - 1);  // clamped: every load is unconditional
+  double ra[NPA], rb[NPB];
+  int32_t kd = wk.k0;   // descendant cursor of the chunk being loaded
+  int32_t kk0 = 0;      // first column of that chunk inside the descendant
+  int kc_ld = 0;        // depth of the chunk held in ra / rb
+  auto load_chunk = [&]() {
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    const int64_t md = S.n - c0d;
+    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
+    kc_ld = min(KC, wd - kk0);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) ra[i] = Pd[(int64_t)min(ka + 2 * i, kc_ld - 1) * md + R0 + ra_row];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) rb[i] = Pd[(int64_t)min(kb + 4 * i, kc_ld - 1) * md + rb_col];
+    kk0 += KC;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+  };
+  auto store_chunk = [&](int b) {
+    double* As = Abuf + b * KC * LDA2;
+    double* Bs = Bbuf + b * KC * LDB;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) As[(ka + 2 * i) * LDA2 + ta] = (ka + 2 * i < kc_ld) ? ra[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) Bs[(kb + 4 * i) * LDB + tb] = (kb + 4 * i < kc_ld) ? rb[i] : 0.0;
+  };
+  // accumulators (64 doubles per lane in both forms)
+  d4 acc16[NJB][2];
+  double acc4[DTR / 16][4];
+  if (MF == 16) {
+#pragma unroll
+    for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  } else {
+#pragma unroll
+    for (int a = 0; a < DTR / 16; ++a)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) acc4[a][q4] = 0.0;
+  }
+  const int li = lane & 15, lk = lane >> 4, l3 = lane & 3;
+  if (wk.k0 >= wk.k1) return;
+  load_chunk();
+  int kc_cur = kc_ld;
+  store_chunk(0);
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    const bool more = kd < wk.k1;
+    if (more) load_chunk();  // global loads of the next chunk in flight during the MFMAs of this one
+    const double* Ac = Abuf + buf * KC * LDA2;
+    const double* Bc = Bbuf + buf * KC * LDB;
+    const int kc4 = (kc_cur + 3) & ~3;
+    if (MFMA && MF == 16) {
+      // wave wv: rows [32 wv, 32 wv + 32) x all 128 columns;  D[M = column][N = row]
+#pragma unroll 2
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        const double a0 = Ac[(k4 + lk) * LDA2 + 32 * wv + li], a1 = Ac[(k4 + lk) * LDA2 + 32 * wv + 16 + li];
+        double b[NJB];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) {
+          acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
+          acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
+        }
+      }
+    } else if (MFMA) {
+      // wave wv: columns [16 wv, 16 wv + 16) x all 256 rows as 16 x 4 pieces of 16 rows x 4 columns
+#pragma unroll 2
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        double cv[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) cv[q4] = Bc[(k4 + lk) * LDB + 16 * wv + 4 * q4 + l3];
+#pragma unroll
+        for (int pr = 0; pr < DTR / 16; ++pr) {
+          const double rv = Ac[(k4 + lk) * LDA2 + 16 * pr + li];
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[q4], rv, acc4[pr][q4], 0, 0, 0);
+        }
+      }
+    } else {
+      // scalar restatement in the layout of the 4x4x4 form (debug path)
+      for (int k = 0; k < kc4; ++k)
+#pragma unroll
+        for (int pr = 0; pr < DTR / 16; ++pr)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] += Bc[k * LDB + 16 * wv + 4 * q4 + lk] * Ac[k * LDA2 + 16 * pr + li];
+    }
+    if (!more) break;
+    store_chunk(buf ^ 1);
+    kc_cur = kc_ld;
+    __syncthreads();
+    buf ^= 1;
+  }
+  // epilogue: tile h = 0 / 1 (rows [128 h, 128 h + 128) of the item) -> panel or its partial slab
+  double* P = L + S.sn_loff[j];
+  auto put = [&](int i, int jc, double v) {
+    const int h = i >> 7;
+    const int32_t slot = h ? wk.slot1 : wk.slot0;
+    if (slot < 0) {
+      if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+    } else if (h < wk.ntiles) {
+      scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+    }
+  };
+  if (MFMA && MF == 16) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put(32 * wv + 16 * ib + li, 16 * jb + lk + 4 * r, acc16[jb][ib][r]);
+  } else {
+#pragma unroll
+    for (int pr = 0; pr < DTR / 16; ++pr)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) put(16 * pr + li, 16 * wv + 4 * q4 + lk, acc4[pr][q4]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Compact path of the supernodal update: combos whose rows / columns are scattered over the target tile
 // (a family subtree updating a few dozen of the 128 x 128 cells' rows and columns) would keep all eight
 // waves and all column blocks of k_update busy although only ceil(nt/16) x ceil(nq/16) blocks carry data.

@@ -459,6 +459,52 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       }
     }
   }
+  // ---------------------------------------------------------------- 7b. dense tail
+  // The trailing clique of a pedigree factor (16.6k columns at the 100k config, 170k at 1M; > 75 % / > 99 % of the
+  // flops) is a chain of fronts whose row lists are "almost every later column".  Padding those lists to EVERY later
+  // column (explicit zeros, like relaxed amalgamation) turns the tail into one dense lower-triangular matrix cut
+  // into block columns: updates inside it need no index lists, no descriptors and no gather.  The tail is grown from
+  // the last front downwards along the chain (parent = next front) while the padded flop count stays within
+  // dense_relax of the true one.
+  S->dense_first = ns;
+  if (opts.dense_relax > 0.0) {
+    double fl_dense = 0.0, fl_true = 0.0;
+    int32_t best = ns;
+    for (int32_t q = ns - 1; q >= 0; --q) {
+      if (q < ns - 1 && S->sn_parent[q] != q + 1) break;
+      const double w = out[q].end - out[q].start, mt = (double)(S->sn_rowptr[q + 1] - S->sn_rowptr[q]), md = (double)(n - out[q].start);
+      fl_dense += w * md * md;
+      fl_true += w * mt * mt;
+      if (fl_dense <= opts.dense_relax * fl_true) best = q;
+      else if (fl_dense > 1.5 * fl_true) break;
+    }
+    if (ns - best >= 4) {
+      // algorithmic update flops of the fronts about to be padded, on their TRUE row lists (same formula as step 10)
+      double true_tail = 0.0;
+      for (int32_t d = 0; d < ns; ++d) {
+        const int64_t rb = S->sn_rowptr[d], re = S->sn_rowptr[d + 1];
+        const int32_t w = out[d].end - out[d].start;
+        int64_t t = rb + w;
+        while (t < re) {
+          const int32_t sq = snode_of[S->sn_rows[t]];
+          int64_t t2 = t;
+          while (t2 < re && snode_of[S->sn_rows[t2]] == sq) ++t2;
+          if (d >= best) {
+            const double nq = (double)(t2 - t), below = (double)(re - t2);
+            true_tail += (double)w * (nq * (nq + 1.0) + 2.0 * nq * below);
+          }
+          t = t2;
+        }
+      }
+      S->update_flops_pad = -true_tail;  // completed in step 10: executed(tail) - true(tail)
+      S->dense_first = best;
+      S->sn_rows.resize((size_t)S->sn_rowptr[best]);
+      for (int32_t q = best; q < ns; ++q) {
+        for (int32_t r = out[q].start; r < n; ++r) S->sn_rows.push_back(r);
+        S->sn_rowptr[q + 1] = (int64_t)S->sn_rows.size();
+      }
+    }
+  }
   lap("row structures");
   // ---------------------------------------------------------------- 8. panel offsets, levels
   S->sn_loff.assign(ns + 1, 0);
@@ -477,14 +523,6 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   }
   S->nlevels = 0;
   for (int32_t s = 0; s < ns; ++s) S->nlevels = std::max(S->nlevels, S->sn_level[s] + 1);
-  // dense tail: the maximal suffix of fronts whose row list is "every column from my first one on" (such a front
-  // cannot be followed by a column that is not its ancestor, so the suffix is a chain with consecutive indices)
-  S->dense_first = ns;
-  while (S->dense_first > 0) {
-    const int32_t q = S->dense_first - 1;
-    if (S->sn_rowptr[q + 1] - S->sn_rowptr[q] != (int64_t)n - out[q].start) break;
-    S->dense_first = q;
-  }
 
   // children lists (increasing order)
   S->child_ptr.assign(ns + 1, 0);
@@ -636,6 +674,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         {
           const double nq = (double)(t2 - t), below = (double)(re - t2);
           S->update_flops += (double)w * (nq * (nq + 1.0) + 2.0 * nq * below);
+          if (d >= S->dense_first) S->update_flops_pad += (double)w * (nq * (nq + 1.0) + 2.0 * nq * below);
         }
         t = t2;
       }

@@ -39,6 +39,7 @@ struct SymbolicOptions {
   double amd_dense = 10.0;     // rows with degree > amd_dense*sqrt(n) are ordered last
   int32_t max_width = SCILMM_NB; // split supernodes wider than this (the kernels' block width; 0 = unlimited)
   int32_t tile_rows = 128;     // rows per target tile of the update kernel
+  double dense_relax = 1.10;   // dense tail: padded / true flop ratio accepted when the trailing chain is made dense (0 = off)
 };
 
 // Everything the numeric phase needs.  "Front" s owns columns [sn_start[s], sn_start[s+1]) of the
@@ -58,9 +59,10 @@ struct Symbolic {
   std::vector<int32_t> sn_rows;   // row lists (sorted; permuted labels)
   std::vector<int64_t> sn_loff;   // [nsuper+1] offsets of the panels in L storage (doubles)
   std::vector<int32_t> sn_level;  // [nsuper] height above the leaves
-  // Fronts [dense_first, nsuper) are the DENSE TAIL: each of them has every later column as a row (m_s = n - start_s),
-  // i.e. together they are one dense lower-triangular matrix cut into block columns (the trailing clique of a
-  // pedigree factor: 16.6k wide at the 100k config, 170k at 1M).  Updates among them need no index lists.
+  // Fronts [dense_first, nsuper) are the DENSE TAIL: each of them has every later column as a row (m_s = n - start_s;
+  // the analysis pads the trailing chain to that, see step 7b), i.e. together they are one dense lower-triangular
+  // matrix cut into block columns (the trailing clique of a pedigree factor: 16.6k wide at the 100k config, 170k at
+  // 1M).  Updates among them need no index lists.
   int32_t dense_first = 0;
   // children lists
   std::vector<int64_t> child_ptr; // [nsuper+1]
@@ -107,7 +109,8 @@ struct Symbolic {
   int64_t nnzL = 0;        // true nonzeros of L (sum colcount)
   int64_t nnzL_stored = 0; // doubles of panel storage (includes relaxation zeros and the upper part of diagonal blocks)
   double flops = 0;        // sum colcount^2
-  double update_flops = 0; // algorithmic flops of all supernodal updates (lower-triangular count)
+  double update_flops = 0; // flops of all supernodal updates as EXECUTED (lower-triangular count; includes the padding of the dense tail)
+  double update_flops_pad = 0;  // part of update_flops that is padding of the dense tail (executed - algorithmic)
   std::string error;
 };
 

@@ -23,7 +23,8 @@ def test_exact_structure_without_relaxation(ordering):
     for trial in range(12):
         n = int(rng.integers(5, 110))
         M = random_spd(n, float(rng.uniform(0.02, 0.3)), trial)
-        sym = Symbolic([M], ordering=ordering, upload=False, relax_small=0, relax_w1=0, relax_w2=0, relax_z3=0.0)
+        sym = Symbolic([M], ordering=ordering, upload=False, relax_small=0, relax_w1=0, relax_w2=0, relax_z3=0.0,
+                       dense_relax=-1.0)
         perm = sym.get("perm")
         assert sorted(perm.tolist()) == list(range(n))
         S = _boolean_cholesky(M, perm)
@@ -106,3 +107,34 @@ def test_empty_and_diagonal_inputs():
     assert info.nnzL == 5 and info.n_updates == 0
     one = sp.csr_matrix(np.array([[2.0]]))
     assert Symbolic([one], upload=False).info().nnzL == 1
+
+
+def test_dense_tail_is_a_padded_chain():
+    """Step 7b of the analysis: the fronts from dense_first on have EVERY later column as a row, form a chain in
+    index order, cover the true structure, and cost at most dense_relax x the true flops of that tail."""
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(10000, 0.01, 5)
+    n = A.shape[0]
+    mats = [A, sp.identity(n, format="csr")]
+    sym = Symbolic(mats, upload=False)
+    ref = Symbolic(mats, upload=False, perm=sym.get("perm"), dense_relax=-1.0)  # same order, no padding
+    df = int(sym.get("dense_first")[0])
+    ns = sym.info().nsuper
+    assert int(ref.get("dense_first")[0]) == ref.info().nsuper
+    assert 0 < df < ns and ns - df >= 4
+    st, rp, rows, par = sym.get("sn_start"), sym.get("sn_rowptr"), sym.get("sn_rows"), sym.get("sn_parent")
+    assert np.array_equal(st, ref.get("sn_start"))
+    rrp, rrows = ref.get("sn_rowptr"), ref.get("sn_rows")
+    fl_dense = fl_true = 0.0
+    for s in range(df, ns):
+        assert np.array_equal(rows[rp[s]:rp[s + 1]], np.arange(st[s], n))
+        assert par[s] == (s + 1 if s + 1 < ns else -1)
+        true_rows = rrows[rrp[s]:rrp[s + 1]]
+        assert np.isin(true_rows, rows[rp[s]:rp[s + 1]]).all()
+        w = st[s + 1] - st[s]
+        fl_dense += w * float(n - st[s]) ** 2
+        fl_true += w * float(true_rows.size) ** 2
+    assert fl_dense <= 1.10 * fl_true
+    for s in range(df):  # everything below the tail is untouched
+        assert np.array_equal(rows[rp[s]:rp[s + 1]], rrows[rrp[s]:rrp[s + 1]])
+    assert sym.info().nnzL == ref.info().nnzL  # the algorithmic count does not include the padding
