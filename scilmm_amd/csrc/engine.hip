@@ -513,8 +513,12 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
               D->world, l0, S.nlevels - 1, S.nlevels - l0, D->world);
   }
   {
+    // k_dense pays from a few hundred tail panels on (300k pedigree: 450 panels, factorization 1.97 -> 1.90 s; 1M: 1330
+    // panels); on a short tail (100k: 135 panels) its one-workgroup-per-CU items balance worse than the explicit
+    // path's (66 -> 72 ms), so it is switched on by the width of the tail.  SCILMM_DENSE=1 / 0 forces it.
     const char* edn = tune_env("SCILMM_DENSE");
-    D->dense_on = S.dense_first < S.nsuper && !(edn && edn[0] == '0');
+    const int32_t tail_w = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
+    D->dense_on = S.dense_first < S.nsuper && (edn ? edn[0] != '0' : tail_w >= 32768);
     const char* emf = tune_env("SCILMM_DENSE_MF");
     if (emf) D->dense_mf = atoi(emf) == 4 ? 4 : 16;
   }

@@ -187,8 +187,9 @@ def test_factorization_is_bitwise_reproducible():
                                  {"SCILMM_UPDATE_VARIANT": "3"}, {"SCILMM_UPDATE_VARIANT": "3", "SCILMM_NO_MFMA": "1"}, {"SCILMM_CELL_LIMIT": "64"},
                                  {"SCILMM_HOST_CELLS": "1"}, {"SCILMM_CELL_LIMIT": "100000"}, {"SCILMM_PUSH_SLICE": "256"},
                                  {"SCILMM_CHAIN_WIDE": "1000", "SCILMM_CHAIN_CAP": "100000"},
-                                 {"SCILMM_DENSE": "0"}, {"SCILMM_DENSE_MF": "4"}, {"SCILMM_DENSE_MF": "16"},
-                                 {"SCILMM_DENSE_MF": "4", "SCILMM_NO_MFMA": "1"}, {"SCILMM_DENSE_MF": "4", "SCILMM_NO_LOOKAHEAD": "1"}])
+                                 {"SCILMM_DENSE": "0"}, {"SCILMM_DENSE": "1", "SCILMM_DENSE_MF": "4"},
+                                 {"SCILMM_DENSE": "1", "SCILMM_DENSE_MF": "16"}, {"SCILMM_DENSE": "1", "SCILMM_NO_MFMA": "1"},
+                                 {"SCILMM_DENSE": "1", "SCILMM_NO_LOOKAHEAD": "1"}])
 def test_alternative_schedules_agree_with_oracle(monkeypatch, env):
     """Every run-time switch selects a different schedule of the SAME arithmetic: all must match the oracle."""
     for k, v in env.items():
