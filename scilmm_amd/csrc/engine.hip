@@ -463,6 +463,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if (ens3 && atoi(ens3) == 3) {
         HIPCHK(hipStreamCreateWithPriority(&D->side3, hipStreamNonBlocking, lo));
         D->nside = 3;
+      } else if (ens3 && atoi(ens3) == 1) {
+        D->nside = 1;  // early updates strictly one after the other (their launch durations then do not overlap)
       }
     }
   }
