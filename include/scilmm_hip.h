@@ -134,6 +134,11 @@ int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r
 /* Y = A_k X, row-major n x r (SparseCholesky.py:66,70,160,163) */
 int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y);
 
+/* Haseman-Elston moments on the device (reference HE, SparseCholesky.py:192-246, REML's starting
+ * point at :121): *frob = sum_ij (A_k1 o A_k2)_ij over the full symmetric matrices, *diag_dot = diag(A_k1) . diag(A_k2),
+ * from the value arrays already resident in HBM (one streaming pass).  y'A_k y comes from scilmm_quadforms. */
+int scilmm_he_moments(scilmm_symbolic* sym, int32_t k1, int32_t k2, double* frob, double* diag_dot);
+
 /* --- device-pointer variants used by bench.py and by callers that keep data resident in HBM */
 int scilmm_solve_dev(scilmm_factor* fac, const double* dB, int32_t r, double* dX);
 int scilmm_lmul_dev(scilmm_factor* fac, const double* dR, int32_t r, double* dZ);
@@ -169,6 +174,16 @@ int scilmm_ibd_sizes(const scilmm_ibd* h, int64_t* nnz_A, int64_t* nnz_L);
 int scilmm_ibd_export(const scilmm_ibd* h, int64_t* a_indptr, int32_t* a_indices, double* a_data, int64_t* l_indptr,
                       int32_t* l_indices, double* l_data, double* D, double* F);
 void scilmm_ibd_free(scilmm_ibd* h);
+
+/* --- the on-disk format in front of the path.  Replaces scipy.io.mmread(path).tocsr()
+ * (scilmm/SparseCholesky.py:399) by a memory-mapped, all-cores parse of the MatrixMarket coordinate file (real /
+ * integer / pattern; general / symmetric / skew-symmetric; duplicates summed, symmetric storage expanded): CSR with
+ * sorted indices.  Host C++/OpenMP; no device needed. */
+typedef struct scilmm_mm scilmm_mm;
+int scilmm_mm_read(const char* path, scilmm_mm** out, int32_t* nrows, int32_t* ncols, int64_t* nnz);
+int scilmm_mm_export(const scilmm_mm* m, int64_t* indptr, int32_t* indices, double* data);
+const char* scilmm_mm_error(const scilmm_mm* m);
+void scilmm_mm_free(scilmm_mm* m);
 
 const char* scilmm_version(void);
 

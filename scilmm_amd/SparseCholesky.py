@@ -254,7 +254,12 @@ def bolt_gradient_estimation(log_sig2g_array, cholesky_func, mats, covariates, y
 
 def estimate_var_comps(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=True, aireml=False):
     """HE start, then L-BFGS-B on log sigma2 (SparseCholesky.py:120-144)."""
-    he_est = HE(mats[:-1], covariates, y, compute_stderr=False)
+    engine = None
+    if _is_hip(cholesky_func):
+        # the analysis is needed for the first evaluation anyway; with the values in HBM the HE moments are two
+        # streaming passes on the device instead of SciPy sparse arithmetic on the host
+        engine = (cholesky_func.engine_for(mats), list(range(len(mats) - 1)))
+    he_est = HE(mats[:-1], covariates, y, compute_stderr=False, engine=engine)
     x0 = np.concatenate((he_est, [1 - he_est.sum()]))
     if np.any(x0 < 0):
         x0 = np.ones((len(mats)))
@@ -325,8 +330,13 @@ def REML(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=Fal
             "covariance std": sigmas_sigmas}
 
 
-def HE(mat_list, cov, y, MQS=False, verbose=False, sim_num=100, compute_stderr=False, y2=None):
+def HE(mat_list, cov, y, MQS=False, verbose=False, sim_num=100, compute_stderr=False, y2=None, engine=None):
     """Haseman-Elston moment estimator (SparseCholesky.py:192-281); REML's starting point (:121).
+
+    ``engine=(symbolic, ks)`` (not in the reference): ``mat_list[i]`` is matrix ``ks[i]`` of a device-resident
+    ``scilmm_amd.factor.Symbolic``; the matrix-sized moments -- ``sum(A_i o A_j)`` and ``y'A_i y`` -- are then one
+    streaming pass each over values already in HBM (``scilmm_he_moments``, ``scilmm_quadforms``) instead of SciPy
+    ``multiply().sum()`` / ``dot`` on the host.  Same estimator, same result to rounding.
 
     The Monte-Carlo standard error follows the evident intent of the reference loop (:259-278), whose
     inner variable shadowing (``mat_i``/``mat_j``) makes it raise for more than one matrix.
@@ -346,7 +356,16 @@ def HE(mat_list, cov, y, MQS=False, verbose=False, sim_num=100, compute_stderr=F
     n = y.shape[0]
     q = np.zeros(K)
     S = np.zeros((K, K))
-    for i, mat_i in enumerate(mat_list):
+    on_device = engine is not None and not MQS and y2 is None and all(sparse.issparse(m) for m in mat_list)
+    if on_device:
+        sym, ks = engine
+        yc = np.ascontiguousarray(y[:, None])
+        for i in range(K):
+            q[i] = sym.quadforms(ks[i], yc)[0] - mat_list[i].diagonal().dot(y ** 2)
+            for j in range(i + 1):
+                fro, dg = sym.he_moments(ks[i], ks[j])
+                S[i, j] = S[j, i] = fro - dg
+    for i, mat_i in enumerate(mat_list if not on_device else []):
         if MQS:
             q[i] = y.dot(mat_i.dot(y)) - y.dot(y)
         elif sparse.issparse(mat_i):
@@ -427,9 +446,23 @@ def run_estimates(A, df_phe, df_cov, reml=False, ignore_indices=False, df_phe2=N
     return he_est
 
 
+def read_relationship_matrix(path):
+    """``mmread(path).tocsr()`` of the reference (SparseCholesky.py:399) -- natively parsed; ``.npz`` also accepted."""
+    if str(path).endswith('.npz'):
+        return sparse.load_npz(path).tocsr()
+    try:
+        return _lib.read_matrix_market(path)
+    except _lib.ScilmmError:
+        return mmread(path).tocsr()  # array-format / complex files: SciPy's general reader
+
+
 def run_estimates_from_paths(A, phe, cov, reml=False, ignore_indices=False):
-    """File front end (SparseCholesky.py:398-403): MatrixMarket A, header-less phenotype CSV, covariate CSV."""
-    A = mmread(A).tocsr()
+    """File front end (SparseCholesky.py:398-403): MatrixMarket A, header-less phenotype CSV, covariate CSV.
+
+    The MatrixMarket file goes through the native streaming parser (``csrc/mmio.cpp``: memory-mapped, all host
+    cores) instead of ``scipy.io.mmread``; a ``.npz`` written by ``scipy.sparse.save_npz`` is accepted behind the
+    same ``--A`` flag (binary, no parsing at all)."""
+    A = read_relationship_matrix(A)
     index_col = None if ignore_indices else 0
     df_cov = pd.read_csv(cov, index_col=index_col)
     df_phe = pd.read_csv(phe, header=None, index_col=index_col)

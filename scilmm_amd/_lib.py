@@ -65,7 +65,8 @@ SYMBOLS = [
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
     "scilmm_order", "scilmm_fill_count",
-    "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external",
+    "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments",
+    "scilmm_mm_read", "scilmm_mm_export", "scilmm_mm_error", "scilmm_mm_free",
 ]
 
 _lib = None
@@ -114,6 +115,13 @@ def lib():
     L.scilmm_ibd_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.scilmm_ibd_free.argtypes = [vp]
     L.scilmm_ibd_free.restype = None
+    L.scilmm_mm_read.argtypes = [C.c_char_p, P(vp), P(i32), P(i32), P(i64)]
+    L.scilmm_mm_export.argtypes = [vp, vp, vp, vp]
+    L.scilmm_mm_error.argtypes = [vp]
+    L.scilmm_mm_error.restype = C.c_char_p
+    L.scilmm_mm_free.argtypes = [vp]
+    L.scilmm_mm_free.restype = None
+    L.scilmm_he_moments.argtypes = [vp, i32, i32, P(dbl), P(dbl)]
     L.scilmm_dist_init.argtypes = [vp, i32, i32, vp, vp, vp]
     L.scilmm_factor_sizes.argtypes = [vp, P(i64), P(i64), P(i64)]
     L.scilmm_factor_create_external.argtypes = [vp, vp, vp, vp, P(vp)]
@@ -177,3 +185,21 @@ def fill_count(A, perm=None):
     check(lib().scilmm_fill_count(A.shape[0], ptr(indptr), ptr(indices), None if p is None else ptr(p), C.byref(nz),
                                   C.byref(fl), C.byref(mx)))
     return nz.value, fl.value, mx.value
+
+
+def read_matrix_market(path):
+    """scipy.io.mmread(path).tocsr() through the native streaming parser (csrc/mmio.cpp)."""
+    import scipy.sparse as sp
+    h = C.c_void_p()
+    nr, nc, nnz = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    st = lib().scilmm_mm_read(os.fsencode(path), C.byref(h), C.byref(nr), C.byref(nc), C.byref(nnz))
+    try:
+        if st != OK:
+            raise ScilmmError("MatrixMarket: " + (lib().scilmm_mm_error(h) or b"read failed").decode())
+        indptr = np.empty(nr.value + 1, dtype=np.int64)
+        indices = np.empty(nnz.value, dtype=np.int32)
+        data = np.empty(nnz.value, dtype=np.float64)
+        check(lib().scilmm_mm_export(h, ptr(indptr), ptr(indices), ptr(data)))
+    finally:
+        lib().scilmm_mm_free(h)
+    return sp.csr_matrix((data, indices, indptr), shape=(nr.value, nc.value))

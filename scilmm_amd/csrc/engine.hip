@@ -961,6 +961,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* emn = tune_env("SCILMM_MIN_ITEM");
     const char* eci = tune_env("SCILMM_COMPACT_ITEM");
     const int64_t compact_item = std::max<int64_t>(1, eci ? atoll(eci) : 32);  // combos per slab-mode compact item
+    const char* edi = tune_env("SCILMM_DENSE_ITEMS");
+    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 2048);  // k_dense items per launch (target)
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -1016,9 +1018,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       const int64_t per_l = allow_split ? std::min(cap_l, std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items)) : big;
       int64_t slots = 0;
       // K segments of the dense-tail items (the same for every tile of the front) and, per tile, their first slab
+      // (their K range is cut so that a launch has about dense_items items: every item writes two 128 KB slabs that
+      // k_reduce reads back, so few long items beat many short ones as long as the launch still fills the chip a
+      // few times over -- measured at the 300k pedigree)
       auto dense_nseg = [&](int32_t cnt, int64_t per_item) -> int64_t {
         if (cnt <= 0) return 0;
-        return std::min<int64_t>(std::min<int64_t>(64, cnt), std::max<int64_t>(1, (dunit * cnt + per_item / 2) / per_item));
+        (void)per_item;
+        const int64_t npairs = dj >= 0 ? (S.tile_base[dj + 1] - S.tile_base[dj] + 1) / 2 : 1;
+        return std::min<int64_t>(std::min<int64_t>(64, cnt), std::max<int64_t>(1, (dense_items + npairs / 2) / npairs));
       };
       const int64_t nde = dense_nseg(dcnt_e, per_e), ndl = dense_nseg(dcnt_l, per_l);
       std::vector<int32_t> dbase_e, dbase_l;  // per tile of front dj: first dense slab, -1 = subtract directly
@@ -2338,6 +2345,39 @@ int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r
   float q = 0;
   HIPCHK(hipEventElapsedTime(&q, D->ev[6], D->ev[7]));
   D->timing.quad_ms = q;
+  return SCILMM_OK;
+}
+
+int scilmm_he_moments(scilmm_symbolic* sym, int32_t k1, int32_t k2, double* frob, double* diag_dot) {
+  if (!sym || !sym->S || !frob || !diag_dot) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  const Symbolic& S = *sym->S;
+  if (k1 < 0 || k1 >= S.K || k2 < 0 || k2 >= S.K || !D->have_vals[k1] || !D->have_vals[k2]) return SCILMM_ERR_STATE;
+  constexpr int NBLK = 1024;
+  st = ensure_io(sym, D, 2 * NBLK);
+  if (st != SCILMM_OK) return st;
+  hipStream_t s0 = D->stream;
+  double* part = D->IO;
+  HIPCHK(hipMemsetAsync(part, 0, sizeof(double) * 2 * NBLK, s0));
+  const bool d1 = S.is_diag[k1], d2 = S.is_diag[k2];
+  // sum over the FULL symmetric matrices = 2 * (sum over the stored lower-triangle slots) - (diagonal part); a
+  // diagonal-only matrix meets any other matrix on the diagonal only
+  if (!d1 && !d2 && S.nnz_pattern > 0)
+    hipLaunchKernelGGL(k_dot_slots, dim3(NBLK), dim3(256), 0, s0, S.nnz_pattern, (const double*)D->vals[k1], (const double*)D->vals[k2], part);
+  if (S.n > 0)
+    hipLaunchKernelGGL(k_dot_diag, dim3(NBLK), dim3(256), 0, s0, S.n, D->v.pat_colptr, (const double*)D->vals[k1], (const double*)D->vals[k2],
+                       d1 ? 1 : 0, d2 ? 1 : 0, part + NBLK);
+  std::vector<double> h(2 * NBLK);
+  HIPCHK(hipMemcpyAsync(h.data(), part, sizeof(double) * 2 * NBLK, hipMemcpyDeviceToHost, s0));
+  HIPCHK(hipStreamSynchronize(s0));
+  HIPCHK(hipGetLastError());
+  long double all = 0.0L, dg = 0.0L;
+  for (int b = 0; b < NBLK; ++b) { all += h[b]; dg += h[NBLK + b]; }
+  *diag_dot = (double)dg;
+  *frob = (d1 || d2) ? (double)dg : (double)(2.0L * all - dg);
   return SCILMM_OK;
 }
 

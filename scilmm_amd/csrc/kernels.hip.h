@@ -901,6 +901,9 @@ struct DenseWork {
   int32_t slot0, slot1;  // partial slab of each tile, or -1: subtract straight from the panel
   int32_t pad;
 };
+#ifndef SCILMM_DENSE_ABL
+#define SCILMM_DENSE_ABL 0  // tuning-harness ablations (csrc/tools/dense_bench.hip only): 1 no epilogue, 2 no global loads, 3 no LDS stores
+#endif
 constexpr int DTR = 2 * TM;        // rows per dense work item
 constexpr int LDA2 = DTR + 16;     // == 16 mod 32 doubles: conflict-free b64 fragment reads
 
@@ -932,10 +935,12 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
     const int64_t md = S.n - c0d;
     const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
     kc_ld = min(KC, wd - kk0);
+    if (SCILMM_DENSE_ABL != 2 || (kd == wk.k0 && kk0 == 0)) {
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) ra[i] = Pd[(int64_t)min(ka + 2 * i, kc_ld - 1) * md + R0 + ra_row];
+      for (int i = 0; i < NPA; ++i) ra[i] = Pd[(int64_t)min(ka + 2 * i, kc_ld - 1) * md + R0 + ra_row];
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) rb[i] = Pd[(int64_t)min(kb + 4 * i, kc_ld - 1) * md + rb_col];
+      for (int i = 0; i < NPB; ++i) rb[i] = Pd[(int64_t)min(kb + 4 * i, kc_ld - 1) * md + rb_col];
+    }
     kk0 += KC;
     if (kk0 >= wd) { kk0 = 0; ++kd; }
   };
@@ -1009,10 +1014,22 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
           for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] += Bc[k * LDB + 16 * wv + 4 * q4 + lk] * Ac[k * LDA2 + 16 * pr + li];
     }
     if (!more) break;
-    store_chunk(buf ^ 1);
+    if (SCILMM_DENSE_ABL != 3) store_chunk(buf ^ 1);
     kc_cur = kc_ld;
     __syncthreads();
     buf ^= 1;
+  }
+  if (SCILMM_DENSE_ABL == 1) {  // keep the accumulators alive without the stores
+    double sacc = 0.0;
+    if (MF == 16) {
+#pragma unroll
+      for (int a = 0; a < NJB; ++a) sacc += acc16[a][0][0] + acc16[a][0][1] + acc16[a][0][2] + acc16[a][0][3] + acc16[a][1][0] + acc16[a][1][1] + acc16[a][1][2] + acc16[a][1][3];
+    } else {
+#pragma unroll
+      for (int a = 0; a < DTR / 16; ++a) sacc += acc4[a][0] + acc4[a][1] + acc4[a][2] + acc4[a][3];
+    }
+    if (sacc == 123.456) scratch[0] = sacc;
+    return;
   }
   // epilogue: tile h = 0 / 1 (rows [128 h, 128 h + 128) of the item) -> panel or its partial slab
   double* P = L + S.sn_loff[j];
@@ -2457,6 +2474,47 @@ __global__ void k_spmm_diag(int32_t n, const double* __restrict__ dvals, const d
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)n * rp) return;
   Y[idx] += dvals[idx / rp] * X[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Haseman-Elston moments (reference HE, scilmm/SparseCholesky.py:192-246: S_ij = sum(A_i o A_j) - diag_i . diag_j,
+// q_i = y'A_i y - diag_i . y^2): the only matrix-sized work is the Frobenius inner product of two value arrays that
+// already sit in HBM in pattern-slot order.  One streaming pass (HBM-bound, 16 B per slot), block partials in a
+// fixed order; the host adds them up.  part[b] = sum over the block's slots of v1 * v2.
+__global__ __launch_bounds__(256) void k_dot_slots(int64_t nnz, const double* __restrict__ v1, const double* __restrict__ v2,
+                                                   double* __restrict__ part) {
+  __shared__ double red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double s0 = 0.0, s1 = 0.0;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e + stride < nnz; e += 2 * stride) {
+    s0 += v1[e] * v2[e];
+    s1 += v1[e + stride] * v2[e + stride];
+  }
+  if (e < nnz) s0 += v1[e] * v2[e];
+  double s = s0 + s1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// diagonal entries: slot pat_colptr[j] is the diagonal of permuted column j.  part[b] = sum_j d1_j * d2_j
+__global__ __launch_bounds__(256) void k_dot_diag(int32_t n, const int64_t* __restrict__ pat_colptr, const double* __restrict__ v1,
+                                                  const double* __restrict__ v2, int diag1, int diag2, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const double a = diag1 ? v1[j] : v1[pat_colptr[j]];  // diagonal-only matrices are stored as one value per row
+    const double b = diag2 ? v2[j] : v2[pat_colptr[j]];
+    s += a * b;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace scilmm

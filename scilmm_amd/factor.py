@@ -98,6 +98,12 @@ class Symbolic(object):
         check(lib().scilmm_quadforms(self._h, k, ptr(U), U.shape[1], ptr(out)), self._h)
         return out
 
+    def he_moments(self, k1, k2):
+        """(sum(A_k1 o A_k2), diag(A_k1) . diag(A_k2)) from the device-resident values (HE, SparseCholesky.py:223-231)."""
+        fro, dg = C.c_double(0.0), C.c_double(0.0)
+        check(lib().scilmm_he_moments(self._h, k1, k2, C.byref(fro), C.byref(dg)), self._h)
+        return fro.value, dg.value
+
     def spmm(self, k, X):
         X = np.asarray(X, dtype=np.float64)
         X2 = np.ascontiguousarray(X.reshape(self.n, -1))

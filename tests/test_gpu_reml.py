@@ -167,3 +167,26 @@ def test_not_positive_definite_surfaces_as_exception():
     V = sp.csr_matrix(np.array([[1.0, 3.0], [3.0, 1.0]]))
     with pytest.raises(NotPositiveDefiniteError):
         P.SparseCholesky(ordering_method="natural")(V)
+
+
+def test_he_moments_on_device_match_host():
+    """HE (SparseCholesky.py:192-246) with the matrix-sized moments taken on the device: same estimate as the host
+    SciPy path to rounding, for one and for two relationship matrices, and equal to the reference's golden value."""
+    from scilmm_amd.factor import Symbolic
+    g, A = _g1()
+    g2 = np.load(os.path.join(GOLD, "G2_lmm_dominance.npz"))
+    D = sp.csr_matrix((g2["D_data"], g2["D_indices"], g2["D_indptr"]), shape=A.shape)
+    n = A.shape[0]
+    I = sp.eye(n).tocsr()
+    y, C = g["y"], g["C"]
+    sym = Symbolic([A, D, I])
+    for mats, ks in (([A], [0]), ([A, D], [0, 1])):
+        host = P.HE(mats, C, y)
+        dev = P.HE(mats, C, y, engine=(sym, ks))
+        assert rel_err(dev, host) < 1e-11
+    assert rel_err(P.HE([A], C, y, engine=(sym, [0])), g["he_est"]) < 1e-8
+    fro, dg = sym.he_moments(0, 1)
+    assert abs(fro - A.multiply(D).sum()) < 1e-11 * abs(fro)
+    assert abs(dg - A.diagonal().dot(D.diagonal())) < 1e-12 * abs(dg)
+    fro_i, dg_i = sym.he_moments(0, 2)   # against the (diagonal-only) identity: the trace of A
+    assert abs(fro_i - A.diagonal().sum()) < 1e-12 * abs(fro_i) and abs(dg_i - fro_i) < 1e-12 * abs(fro_i)

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 from scilmm_amd.harness import pedigree as H
@@ -76,3 +77,36 @@ def test_native_ibd_rejects_unordered_pedigree():
     from scilmm_amd._lib import ScilmmError
     with pytest.raises(ScilmmError):
         N.ibd_from_parents(np.array([[1, -1], [-1, -1]]))  # child listed before its parent
+
+
+def test_native_matrix_market_reader_matches_scipy(tmp_path):
+    """csrc/mmio.cpp behind --A (reference: mmread(A).tocsr(), SparseCholesky.py:399): general / symmetric / pattern /
+    integer files, comments, blank lines, duplicates, CRLF, empty rows."""
+    import scipy.io as sio
+    import scipy.sparse as sp
+    from scilmm_amd import _lib
+    rng = np.random.default_rng(0)
+    M = sp.random(300, 300, density=0.05, random_state=1, format="coo")
+    S = (M + M.T).tocoo()
+    cases = {"general": M, "symmetric": S}
+    for name, mat in cases.items():
+        path = str(tmp_path / (name + ".mtx"))
+        sio.mmwrite(path, mat, symmetry="symmetric" if name == "symmetric" else "general", precision=17)
+        got = _lib.read_matrix_market(path)
+        ref = sio.mmread(path).tocsr()
+        ref.sort_indices()
+        assert got.shape == ref.shape and np.array_equal(got.indptr, ref.indptr)
+        assert np.array_equal(got.indices, ref.indices) and np.array_equal(got.data, ref.data)
+    # hand-written file: comments, blank line, duplicate entry, CRLF, pattern field, integer field
+    p1 = tmp_path / "pat.mtx"
+    p1.write_text("%%MatrixMarket matrix coordinate pattern general\n% a comment\n\n4 5 4\n1 1\n2 3\r\n4 5\n2 3\n")
+    got = _lib.read_matrix_market(str(p1))
+    assert got.shape == (4, 5) and got.nnz == 3 and got[1, 2] == 2.0 and got[0, 0] == 1.0 and got[3, 4] == 1.0
+    p2 = tmp_path / "int.mtx"
+    p2.write_text("%%MatrixMarket matrix coordinate integer skew-symmetric\n3 3 2\n2 1 7\n3 2 -4\n")
+    got = _lib.read_matrix_market(str(p2)).toarray()
+    assert np.array_equal(got, np.array([[0, -7, 0], [7, 0, 4], [0, -4, 0]], dtype=float))
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")
+    with pytest.raises(_lib.ScilmmError):
+        _lib.read_matrix_market(str(bad))
