@@ -890,7 +890,8 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update3(DevSy
 // target's columns): 21 flop per staged byte instead of 16, and one workgroup per CU so that the accumulators
 // (64 doubles per lane) and a whole chunk of global loads in flight fit the register file.  The K dimension is
 // streamed in chunks of KC through a double-buffered k-major LDS image; the loads of chunk c+1 are issued before the
-// MFMAs of chunk c and written to the other buffer after them (one barrier per chunk).
+// MFMAs of chunk c and written to the other buffer after them (one barrier per chunk).  (The k_update2-style schedule
+// -- stores and re-loads interleaved with the k-steps -- was measured here too: 50 instead of 55 TFLOP/s in isolation.)
 // MF selects the matrix instruction: 16 = v_mfma_f64_16x16x4_f64 (wave = 32 rows x 128 columns), 4 =
 // v_mfma_f64_4x4x4f64 (wave = 16 columns x 256 rows, see k_update3).
 struct DenseWork {
@@ -907,6 +908,9 @@ struct DenseWork {
 constexpr int DTR = 2 * TM;        // rows per dense work item
 constexpr int LDA2 = DTR + 16;     // == 16 mod 32 doubles: conflict-free b64 fragment reads
 
+#ifdef SCILMM_DENSE_CLK
+__device__ unsigned long long g_dense_clk[2];  // tuning harness only: summed wall-clock (100 MHz) / shader-clock ticks of wave 0
+#endif
 template <int MF, bool MFMA>
 __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
                                                   double* __restrict__ L, double* __restrict__ scratch) {
@@ -914,6 +918,9 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
   double* Abuf = smem;                      // [2][KC][LDA2]
   double* Bbuf = smem + 2 * KC * LDA2;      // [2][KC][LDB]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef SCILMM_DENSE_CLK
+  const unsigned long long clk_w0 = wall_clock64(), clk_c0 = clock64();
+#endif
   const DenseWork wk = work[blockIdx.x];
   const int32_t j = wk.front;
   const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
@@ -1031,6 +1038,12 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
     if (sacc == 123.456) scratch[0] = sacc;
     return;
   }
+#ifdef SCILMM_DENSE_CLK
+  if (tid == 0) {
+    atomicAdd(&g_dense_clk[0], wall_clock64() - clk_w0);
+    atomicAdd(&g_dense_clk[1], clock64() - clk_c0);
+  }
+#endif
   // epilogue: tile h = 0 / 1 (rows [128 h, 128 h + 128) of the item) -> panel or its partial slab
   double* P = L + S.sn_loff[j];
   auto put = [&](int i, int jc, double v) {

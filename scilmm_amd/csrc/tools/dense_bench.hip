@@ -9,6 +9,15 @@
 #include "../kernels.hip.h"
 using namespace scilmm;
 
+// operands: 0 = zeros (read HIGH: zero MFMA operands raise the clock), 1 = full-range uniform [-1, 1)
+__global__ void k_fill(double* p, size_t n, int mode) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long x = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+    p[i] = mode == 0 ? 0.0 : ((double)(x >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0;
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -58,8 +67,12 @@ int main(int argc, char** argv) {
   for (auto& w : work) flops += 2.0 * (w.ntiles * TM) * NB * (double)NB * (w.k1 - w.k0);
   printf("T=%d panels, target %d: %zu items (%d descendants each), %.3f TFLOP per launch, %.1f MB of slabs\n", T, j, work.size(), per,
          flops / 1e12, slot * TM * NB * 8 / 1e6);
-  for (int mf : {16, 4})
+  for (int fill : {0, 1})
+  for (int mf : {16, 4}) {
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, (size_t)sn_loff[T], fill);
     for (int rep = 0; rep < 3; ++rep) {
+      unsigned long long z[2] = {0, 0};
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dense_clk), z, sizeof(z)));
       hipEventRecord(e0);
       if (mf == 16) hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
       else hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
@@ -68,7 +81,10 @@ int main(int argc, char** argv) {
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       CK(hipGetLastError());
-      if (rep) printf("k_dense<%d>: %.3f ms -> %.2f TFLOP/s\n", mf, ms, flops / ms / 1e9);
+      CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_dense_clk), sizeof(z)));
+      if (rep) printf("k_dense<%d>, %s operands: %.3f ms -> %.2f TFLOP/s at %.2f GHz shader clock\n", mf, fill ? "random" : "zero", ms,
+                      flops / ms / 1e9, 0.1 * (double)z[1] / (double)z[0]);
     }
+  }
   return 0;
 }
