@@ -225,12 +225,22 @@ void dev_free(void* p) {
 }
 
 // Expand the small combos to the cell lists of k_sparse_cells on the device (see cellplan.hip.h).
-int build_cells_device(scilmm_symbolic* sym, Dev* D, const std::vector<CellCombo>& cc, int32_t NL, int64_t* ngroups_total,
-                       int64_t* n_early) {
+// (ccparts: the small combos as the classification threads produced them, in tile order; they are uploaded part by
+// part -- concatenating 17 GB of them on the host first cost seconds of every first evaluation at the 1M config)
+int build_cells_device(scilmm_symbolic* sym, Dev* D, const std::vector<const std::vector<CellCombo>*>& ccparts, int32_t NL,
+                       int64_t* ngroups_total, int64_t* n_early) {
   const Symbolic& S = *sym->S;
-  const int64_t ncc = (int64_t)cc.size();
+  int64_t ncc = 0;
+  for (auto* pv : ccparts) ncc += (int64_t)pv->size();
   std::vector<int64_t> off((size_t)ncc + 1, 0);
-  for (int64_t c = 0; c < ncc; ++c) off[(size_t)c + 1] = off[(size_t)c] + (int64_t)cc[(size_t)c].nt * cc[(size_t)c].nq;
+  {
+    int64_t c = 0;
+    for (auto* pv : ccparts)
+      for (const CellCombo& q : *pv) {
+        off[(size_t)c + 1] = off[(size_t)c] + (int64_t)q.nt * q.nq;
+        ++c;
+      }
+  }
   const int64_t total = off[(size_t)ncc];
   auto dmalloc = [&](void** p, size_t bytes) -> int {
     HIPCHK(hipMalloc(p, std::max<size_t>(bytes, 8)));
@@ -272,7 +282,13 @@ int build_cells_device(scilmm_symbolic* sym, Dev* D, const std::vector<CellCombo
   int64_t *cst = nullptr, *csq = nullptr; int32_t *cmd = nullptr, *cwd = nullptr;
   if ((st = tmalloc((void**)&d_cc, sizeof(CellCombo) * (size_t)ncc)) != SCILMM_OK) return st;
   if ((st = tmalloc((void**)&d_off, sizeof(int64_t) * (size_t)(ncc + 1))) != SCILMM_OK) return st;
-  HIPCHK(hipMemcpy(d_cc, cc.data(), sizeof(CellCombo) * (size_t)ncc, hipMemcpyHostToDevice));
+  {
+    size_t at = 0;
+    for (auto* pv : ccparts) {
+      if (!pv->empty()) HIPCHK(hipMemcpy(d_cc + at, pv->data(), sizeof(CellCombo) * pv->size(), hipMemcpyHostToDevice));
+      at += pv->size();
+    }
+  }
   HIPCHK(hipMemcpy(d_off, off.data(), sizeof(int64_t) * (size_t)(ncc + 1), hipMemcpyHostToDevice));
   if ((st = tmalloc((void**)&key, 8 * (size_t)total)) != SCILMM_OK) return st;
   if ((st = tmalloc((void**)&skey, 8 * (size_t)total)) != SCILMM_OK) return st;
@@ -659,7 +675,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // host enumeration (same lists up to the order of the contributions inside a group).
     const char* ehc = tune_env("SCILMM_HOST_CELLS");
     const bool gpu_cells = !(ehc && ehc[0] == '1') && S.nnzL_stored < ((int64_t)1 << 38);
-    std::vector<CellCombo> cellcombos;
+    std::vector<std::vector<CellCombo>> cellparts;  // the small combos, one vector per classification thread (tile order)
+    std::vector<uint8_t> cd_cost;                   // per dense-path combo: 1 + K chunks (what the work-item cuts need)
+    int64_t n_dense_total = 0;
     auto process_range = [&](int64_t gbeg, int64_t gend, Part& Pt) {
     std::vector<ComboDesc>& cd = Pt.cd;
     std::vector<ComboDesc>& ccd = Pt.ccd;
@@ -783,29 +801,51 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       for (auto& th : pool) th.join();
       size_t ncd = 0, nccd = 0, ncell = 0;
       for (auto& Pt : parts) { ncd += Pt.cd.size(); nccd += Pt.ccd.size(); ncell += Pt.cells.size(); }
-      cd.reserve(ncd + 1);
       ccd.reserve(nccd + 1);
       cells.reserve(ncell);
+      // The dense-path descriptors (18 GB at the 1M config) are NOT concatenated on the host: every part goes straight
+      // to its place in the device array, and the host keeps one byte per combo (its cost) for the work-item cuts.
+      {
+        void* pdc = nullptr;
+        HIPCHK(hipMalloc(&pdc, sizeof(ComboDesc) * (ncd + 1)));
+        D->allocs.push_back(pdc);
+        D->d_combos = (ComboDesc*)pdc;
+      }
+      cd_cost.resize(ncd);
+      std::vector<int64_t> dbases(nth + 1, 0);
+      for (unsigned k = 0; k < nth; ++k) dbases[k + 1] = dbases[k] + (int64_t)parts[k].cd.size();
+      {
+        std::vector<std::thread> pool2;
+        auto fill_cost = [&](unsigned k) {
+          const std::vector<ComboDesc>& v = parts[k].cd;
+          uint8_t* dst = cd_cost.data() + dbases[k];
+          for (size_t c = 0; c < v.size(); ++c) dst[c] = (uint8_t)(1 + (v[c].wd + KC - 1) / KC);
+        };
+        for (unsigned k = 1; k < nth; ++k) pool2.emplace_back(fill_cost, k);
+        fill_cost(0);
+        for (auto& th : pool2) th.join();
+      }
       for (unsigned k = 0; k < nth; ++k) {
         Part& Pt = parts[k];
-        const int64_t dbase = (int64_t)cd.size(), cbase = (int64_t)ccd.size();
+        const int64_t dbase = dbases[k], cbase = (int64_t)ccd.size();
         for (int64_t g = cut[k]; g < cut[k + 1]; ++g) {
           dmid[g] = dbase + Pt.dmidv[(size_t)(g - cut[k])];
           dptr[g + 1] = dbase + Pt.dend[(size_t)(g - cut[k])];
           for (int k4 = 0; k4 < 4; ++k4) cptr[4 * g + k4 + 1] = cbase + Pt.cend[(size_t)(4 * (g - cut[k]) + k4)];
         }
-        cd.insert(cd.end(), Pt.cd.begin(), Pt.cd.end());
+        if (!Pt.cd.empty())
+          HIPCHK(hipMemcpy(D->d_combos + dbase, Pt.cd.data(), sizeof(ComboDesc) * Pt.cd.size(), hipMemcpyHostToDevice));
         ccd.insert(ccd.end(), Pt.ccd.begin(), Pt.ccd.end());
         cells.insert(cells.end(), Pt.cells.begin(), Pt.cells.end());
-        cellcombos.insert(cellcombos.end(), Pt.cellcombos.begin(), Pt.cellcombos.end());
-        std::vector<CellCombo>().swap(Pt.cellcombos);
         D->n_sparse_combos += Pt.n_sparse;
         D->n_compact_combos += Pt.n_compact;
         Part().cd.swap(Pt.cd);
         std::vector<Cell>().swap(Pt.cells);
       }
+      n_dense_total = (int64_t)ncd;
+      for (unsigned k = 0; k < nth; ++k) cellparts.push_back(std::move(parts[k].cellcombos));
     }
-    D->n_dense_combos = (int64_t)cd.size();
+    D->n_dense_combos = n_dense_total;
 
     D->n_cells = (int64_t)cells.size();
     plap("classify combos, list cells");
@@ -813,15 +853,19 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     int64_t ngroups_total = 0;
     if (gpu_cells) {
       int64_t potential = 0;
-      for (const CellCombo& q : cellcombos) potential += (int64_t)q.nt * q.nq;
+      std::vector<const std::vector<CellCombo>*> ccparts;
+      for (auto& pv : cellparts) {
+        ccparts.push_back(&pv);
+        for (const CellCombo& q : pv) potential += (int64_t)q.nt * q.nq;
+      }
       if (potential >= ((int64_t)1 << 31)) {
         sym->err = "cell plan: more than 2^31 cells (raise SCILMM_CELL_LIMIT granularity or set SCILMM_HOST_CELLS=1)";
         return SCILMM_ERR_ARG;
       }
       int64_t n_early_groups = 0;
-      if ((st = build_cells_device(sym, D, cellcombos, std::max(S.nlevels, 1), &ngroups_total, &n_early_groups)) != SCILMM_OK) return st;
+      if ((st = build_cells_device(sym, D, ccparts, std::max(S.nlevels, 1), &ngroups_total, &n_early_groups)) != SCILMM_OK) return st;
       split = (size_t)n_early_groups;
-      std::vector<CellCombo>().swap(cellcombos);
+      std::vector<std::vector<CellCombo>>().swap(cellparts);
     } else {
       // Cells are ordered by (late class, level, dst, st, sq): counting sort on (class, level), then every bucket is
       // sorted, cut into groups of equal target address (short groups first) and written to the upload arrays
@@ -926,10 +970,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       std::vector<Cell>().swap(cells);
       plap("sort/group/upload cells");
     }
-    if (cd.empty()) cd.push_back(ComboDesc{});
-    const ComboDesc* dc;
-    if ((st = upload(sym, D, cd, &dc)) != SCILMM_OK) return st;
-    D->d_combos = (ComboDesc*)dc;
     const int64_t ntiles = (int64_t)S.tile_front.size();
     std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
     std::vector<int32_t> pslot_e(pslot.size(), 0), pnseg_e(pslot.size(), 0), red_tiles_e;
@@ -952,7 +992,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Each launch (the early
     // and the late part of a level) is cut into about 4 work items per CU of equal cost, so that one launch
     // fills the chip once with balanced items (late levels of a dense chain: few tiles, long combo lists).
-    auto combo_cost_d = [&](int64_t c) -> int64_t { return 1 + (cd[c].wd + KC - 1) / KC; };
+    auto combo_cost_d = [&](int64_t c) -> int64_t { return cd_cost[(size_t)c]; };
     auto combo_cost = [&](int64_t c) -> int64_t { return combo_cost_d(c); };
     // ... but an item never exceeds max_item units (~0.5 ms): the main stream's kernels start in the slots that
     // retiring update items free, so long items starve the per-level chain (300k probe: 2.3 ms per trsm launch)
@@ -2144,7 +2184,17 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) 
   {
     const auto& slot = S.val_slot[k];
     const auto& src = S.val_src[k];
-    for (size_t t = 0; t < slot.size(); ++t) h[slot[t]] = data_k[src[t]];
+    // every pattern slot is written by exactly one entry: the permutation is split over a few host threads
+    const size_t cnt = slot.size();
+    const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), cnt / (1 << 20) + 1));
+    auto part = [&](unsigned q) {
+      const size_t a = cnt * q / nth, b = cnt * (q + 1) / nth;
+      for (size_t t = a; t < b; ++t) h[slot[t]] = data_k[src[t]];
+    };
+    std::vector<std::thread> pool;
+    for (unsigned q = 1; q < nth; ++q) pool.emplace_back(part, q);
+    part(0);
+    for (auto& th : pool) th.join();
   }
   if (!D->vals[k]) HIPCHK(hipMalloc((void**)&D->vals[k], std::max<size_t>(h.size(), 1) * sizeof(double)));
   if (!h.empty()) HIPCHK(hipMemcpy(D->vals[k], h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));

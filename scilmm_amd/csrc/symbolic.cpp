@@ -23,13 +23,18 @@ namespace {
 // CSC-lower (strict or with diagonal) <-> CSR-lower transpose of a pattern.
 void transpose_pattern(int32_t n, const std::vector<int64_t>& ptr, const std::vector<int32_t>& idx,
                        std::vector<int64_t>& tptr, std::vector<int32_t>& tidx) {
+  // (count and fill with relaxed atomics on all host cores; the lists of a row come out in arbitrary order, which
+  // its only reader -- Liu's elimination-tree algorithm -- does not depend on)
   tptr.assign(n + 1, 0);
-  for (int64_t e = 0; e < (int64_t)idx.size(); ++e) tptr[idx[e] + 1]++;
+  const int64_t nz = (int64_t)idx.size();
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < nz; ++e) __atomic_fetch_add(&tptr[idx[e] + 1], 1, __ATOMIC_RELAXED);
   for (int32_t i = 0; i < n; ++i) tptr[i + 1] += tptr[i];
   tidx.resize(idx.size());
   std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+#pragma omp parallel for schedule(dynamic, 4096)
   for (int32_t j = 0; j < n; ++j)
-    for (int64_t e = ptr[j]; e < ptr[j + 1]; ++e) tidx[fill[idx[e]]++] = j;
+    for (int64_t e = ptr[j]; e < ptr[j + 1]; ++e) tidx[__atomic_fetch_add(&fill[idx[e]], 1, __ATOMIC_RELAXED)] = j;
 }
 
 // Liu's algorithm. rptr/ridx: for each row i the columns k < i with A_ik != 0.
@@ -294,23 +299,26 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   lap("ordering");
   // ---------------------------------------------------------------- 3. permuted strict-lower pattern by column
   auto build_csc = [&](const std::vector<int32_t>& ip, std::vector<int64_t>& cptr, std::vector<int32_t>& cidx) {
+    // count / fill on all host cores (relaxed atomics; the per-column sort below makes the result deterministic)
     cptr.assign(n + 1, 0);
+#pragma omp parallel for schedule(dynamic, 4096)
     for (int32_t i = 0; i < n; ++i)
       for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
         int32_t j = uidx[e];
         if (j == i) continue;
         int32_t a = ip[i], b = ip[j];
-        cptr[std::min(a, b) + 1]++;
+        __atomic_fetch_add(&cptr[std::min(a, b) + 1], 1, __ATOMIC_RELAXED);
       }
     for (int32_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
     cidx.resize(cptr[n]);
     std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
+#pragma omp parallel for schedule(dynamic, 4096)
     for (int32_t i = 0; i < n; ++i)
       for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
         int32_t j = uidx[e];
         if (j == i) continue;
         int32_t a = ip[i], b = ip[j];
-        cidx[fill[std::min(a, b)]++] = std::max(a, b);
+        cidx[__atomic_fetch_add(&fill[std::min(a, b)], 1, __ATOMIC_RELAXED)] = std::max(a, b);
       }
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int32_t j = 0; j < n; ++j) std::sort(cidx.begin() + cptr[j], cidx.begin() + cptr[j + 1]);
@@ -585,24 +593,27 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       // bucket the stored lower entries of matrix k by permuted column, sort each bucket by permuted
       // row and merge it against the (sorted) pattern column: cache-friendly, O(nnz log colsize).
       std::vector<int64_t> bptr(n + 1, 0);
+#pragma omp parallel for schedule(dynamic, 4096)
       for (int32_t i = 0; i < n; ++i)
         for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
           int32_t j = indices[k][e];
           if (j > i || j < 0) continue;
-          bptr[std::min(iperm[i], iperm[j]) + 1]++;
+          __atomic_fetch_add(&bptr[std::min(iperm[i], iperm[j]) + 1], 1, __ATOMIC_RELAXED);
         }
       for (int32_t c = 0; c < n; ++c) bptr[c + 1] += bptr[c];
       const int64_t cntk = bptr[n];
       std::vector<int32_t> brow(cntk);
       std::vector<int64_t> bsrc(cntk);
       {
+        // (relaxed atomics on all cores; every bucket is sorted by (row, source) below, so the maps are deterministic)
         std::vector<int64_t> fill(bptr.begin(), bptr.end() - 1);
+#pragma omp parallel for schedule(dynamic, 4096)
         for (int32_t i = 0; i < n; ++i)
           for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
             int32_t j = indices[k][e];
             if (j > i || j < 0) continue;
             int32_t a = iperm[i], b = iperm[j];
-            int64_t f = fill[std::min(a, b)]++;
+            int64_t f = __atomic_fetch_add(&fill[std::min(a, b)], 1, __ATOMIC_RELAXED);
             brow[f] = std::max(a, b);
             bsrc[f] = e;
           }

@@ -58,10 +58,10 @@ __global__ __launch_bounds__(512, 1) void k_mix(double* out, unsigned long long*
   double s = 0;
   if (MF == 16) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) s += acc16[a][0][0] + acc16[a][1][3];
+    for (int a = 0; a < 8; ++a) s += acc16[a][0][0] + acc16[a][0][1] + acc16[a][0][2] + acc16[a][0][3] + acc16[a][1][0] + acc16[a][1][1] + acc16[a][1][2] + acc16[a][1][3];
   } else {
 #pragma unroll
-    for (int a = 0; a < 16; ++a) s += acc4[a][0] + acc4[a][3];
+    for (int a = 0; a < 16; ++a) s += acc4[a][0] + acc4[a][1] + acc4[a][2] + acc4[a][3];  // every accumulator is live
   }
   out[blockIdx.x * 512 + tid] = s;
   if (lane == 0) { ticks[(blockIdx.x * 8 + wv) * 2] = w1 - w0; ticks[(blockIdx.x * 8 + wv) * 2 + 1] = c1 - c0; }
