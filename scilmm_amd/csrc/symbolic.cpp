@@ -20,6 +20,10 @@ namespace scilmm {
 
 namespace {
 
+// team size of the bucket passes that count / fill with relaxed atomics: beyond a socket's worth of cores the cache-line
+// traffic of the shared counters costs more than the extra threads bring (measured on the 256-core GPU host)
+constexpr int BUCKET_THREADS = 16;
+
 // CSC-lower (strict or with diagonal) <-> CSR-lower transpose of a pattern.
 void transpose_pattern(int32_t n, const std::vector<int64_t>& ptr, const std::vector<int32_t>& idx,
                        std::vector<int64_t>& tptr, std::vector<int32_t>& tidx) {
@@ -27,12 +31,12 @@ void transpose_pattern(int32_t n, const std::vector<int64_t>& ptr, const std::ve
   // its only reader -- Liu's elimination-tree algorithm -- does not depend on)
   tptr.assign(n + 1, 0);
   const int64_t nz = (int64_t)idx.size();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(BUCKET_THREADS)
   for (int64_t e = 0; e < nz; ++e) __atomic_fetch_add(&tptr[idx[e] + 1], 1, __ATOMIC_RELAXED);
   for (int32_t i = 0; i < n; ++i) tptr[i + 1] += tptr[i];
   tidx.resize(idx.size());
   std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
   for (int32_t j = 0; j < n; ++j)
     for (int64_t e = ptr[j]; e < ptr[j + 1]; ++e) tidx[__atomic_fetch_add(&fill[idx[e]], 1, __ATOMIC_RELAXED)] = j;
 }
@@ -301,7 +305,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   auto build_csc = [&](const std::vector<int32_t>& ip, std::vector<int64_t>& cptr, std::vector<int32_t>& cidx) {
     // count / fill on all host cores (relaxed atomics; the per-column sort below makes the result deterministic)
     cptr.assign(n + 1, 0);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
     for (int32_t i = 0; i < n; ++i)
       for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
         int32_t j = uidx[e];
@@ -312,7 +316,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     for (int32_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
     cidx.resize(cptr[n]);
     std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
     for (int32_t i = 0; i < n; ++i)
       for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
         int32_t j = uidx[e];
@@ -593,7 +597,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       // bucket the stored lower entries of matrix k by permuted column, sort each bucket by permuted
       // row and merge it against the (sorted) pattern column: cache-friendly, O(nnz log colsize).
       std::vector<int64_t> bptr(n + 1, 0);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
       for (int32_t i = 0; i < n; ++i)
         for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
           int32_t j = indices[k][e];
@@ -607,7 +611,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       {
         // (relaxed atomics on all cores; every bucket is sorted by (row, source) below, so the maps are deterministic)
         std::vector<int64_t> fill(bptr.begin(), bptr.end() - 1);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
         for (int32_t i = 0; i < n; ++i)
           for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
             int32_t j = indices[k][e];
