@@ -111,8 +111,6 @@ struct Dev {
   hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
   std::vector<hipEvent_t> done_ev;      // per level: kernels of an owned chain level finished (main stream)
   // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
-  hipStream_t dense_st = nullptr;       // the early k_dense launches run back to back on their own stream
-  std::vector<hipEvent_t> dense_ev;     // per level: early k_dense of the level finished
   bool dense_on = false;
   int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
   DenseWork* d_dwork_e = nullptr;
@@ -217,9 +215,6 @@ void dev_free(void* p) {
   for (auto& cs : D->cside)
     if (cs) (void)hipStreamDestroy(cs);
   if (D->rest) (void)hipStreamDestroy(D->rest);
-  if (D->dense_st) (void)hipStreamDestroy(D->dense_st);
-  for (auto& e : D->dense_ev)
-    if (e) (void)hipEventDestroy(e);
   if (D->h_chain_err) (void)hipHostFree(D->h_chain_err);
   for (auto& e : D->chain_ev)
     if (e) (void)hipEventDestroy(e);
@@ -493,13 +488,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     int lo2 = 0, hi2 = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo2, &hi2));
     HIPCHK(hipStreamCreateWithPriority(&D->rest, hipStreamNonBlocking, hi2));
-  }
-  {
-    int lo3 = 0, hi3 = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo3, &hi3));
-    HIPCHK(hipStreamCreateWithPriority(&D->dense_st, hipStreamNonBlocking, lo3));
-    D->dense_ev.assign((size_t)std::max(sym->S->nlevels, 1), nullptr);
-    for (auto& e : D->dense_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   D->chain_ev.assign((size_t)3 * std::max(sym->S->nlevels, 1), nullptr);
   for (auto& e : D->chain_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1586,9 +1574,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   for (auto& cs : D->cside)
     if (cs) HIPCHK(hipStreamWaitEvent(cs, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
-  HIPCHK(hipStreamWaitEvent(D->dense_st, D->ev_asm, 0));
   const bool prof = D->profiling;
-  constexpr int PE = 10;  // profiling events per level
+  constexpr int PE = 8;  // profiling events per level
   if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
     size_t old = D->pev.size();
     D->pev.resize((size_t)PE * S.nlevels, nullptr);
@@ -1662,7 +1649,6 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   };
   // Look-ahead: the EARLY part of level l+1 (descendants finished at levels <= l-1) runs on the side stream
   // while the main stream works through level l's latency-bound tail (late update, reduce, cells, potrf, trsm).
-  int32_t half_last[3] = {-1, -1, -1};  // last level whose early work used each scratch half
   auto launch_early = [&](int32_t l) -> int {
     const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
     if (!has_early(l)) return SCILMM_OK;
@@ -1684,23 +1670,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
+    launch_dense(sd, D->d_dwork_e + D->dwork_e_ptr[l], D->dwork_e_ptr[l + 1] - D->dwork_e_ptr[l], D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
-    const int64_t nde_l = D->dwork_e_ptr[l + 1] - D->dwork_e_ptr[l];
-    if (nde_l > 0) {
-      // The k_dense launches of consecutive levels would only time-slice the chip if they overlapped (one launch
-      // fills it, one workgroup per CU): they run back to back on ONE stream, and the two side streams overlap them
-      // with the explicit items / reduce / cells of the neighbouring levels.  The launch needs its sources and the
-      // scratch half it writes (free once the early work of the level that used it last has been folded).
-      hipStream_t ds = D->dense_st;
-      if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(ds, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
-      if (half_last[sidx] >= 0) HIPCHK(hipStreamWaitEvent(ds, D->lev_ev[2 * half_last[sidx] + 1], 0));
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 8], ds));
-      launch_dense(ds, D->d_dwork_e + D->dwork_e_ptr[l], nde_l, D->scratch + (size_t)sidx * half);
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 9], ds));
-      HIPCHK(hipEventRecord(D->dense_ev[l], ds));
-      HIPCHK(hipStreamWaitEvent(sd, D->dense_ev[l], 0));
-    }
-    half_last[sidx] = l;
     if (slab_compact) HIPCHK(hipStreamWaitEvent(sd, D->chain_ev[3 * l], 0));
     {
       // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
@@ -1874,7 +1845,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   const Symbolic& S = *sym->S;
   hipStream_t st = D->stream;
   const bool prof = D->profiling;
-  constexpr int PE = 10;
+  constexpr int PE = 8;
   fac->pending = false;
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(D->side));
@@ -1884,7 +1855,6 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   for (auto& cs : D->cside)
     if (cs) HIPCHK(hipStreamSynchronize(cs));
   if (D->world > 1 && D->comm) HIPCHK(hipStreamSynchronize(D->comm));
-  HIPCHK(hipStreamSynchronize(D->dense_st));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));
@@ -1901,15 +1871,10 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
         tu += x;
         nu += (D->work_ptr[l + 1] > D->work_ptr[l]) + (D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]);
       }
-      if (D->early_ptr[l + 1] > D->early_ptr[l]) {
+      if (D->early_ptr[l + 1] > D->early_ptr[l] || D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
         HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 5], D->pev[PE * l + 6]));
         tu += x;
-        nu++;
-      }
-      if (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
-        HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 8], D->pev[PE * l + 9]));
-        tu += x;
-        nu++;
+        nu += (D->early_ptr[l + 1] > D->early_ptr[l]) + (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]);
       }
       HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 1], D->pev[PE * l + 2]));
       tmid += x;
@@ -1933,14 +1898,9 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
           HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 1]));
           iv.push_back({a0, a1});
         }
-        if (D->early_ptr[l + 1] > D->early_ptr[l]) {
+        if (D->early_ptr[l + 1] > D->early_ptr[l] || D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
           HIPCHK(hipEventElapsedTime(&a0, D->ev[1], D->pev[PE * l + 5]));
           HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 6]));
-          iv.push_back({a0, a1});
-        }
-        if (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
-          HIPCHK(hipEventElapsedTime(&a0, D->ev[1], D->pev[PE * l + 8]));
-          HIPCHK(hipEventElapsedTime(&a1, D->ev[1], D->pev[PE * l + 9]));
           iv.push_back({a0, a1});
         }
       }
@@ -1967,11 +1927,6 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
           float xe = 0, xl = 0, xm = 0, xp = 0, xt = 0;
           if (D->work_ptr[l + 1] > D->work_ptr[l]) HIPCHK(hipEventElapsedTime(&xl, D->pev[PE * l + 0], D->pev[PE * l + 1]));
           if (D->early_ptr[l + 1] > D->early_ptr[l]) HIPCHK(hipEventElapsedTime(&xe, D->pev[PE * l + 5], D->pev[PE * l + 6]));
-          if (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
-            float xd = 0;
-            HIPCHK(hipEventElapsedTime(&xd, D->pev[PE * l + 8], D->pev[PE * l + 9]));
-            xe += xd;
-          }
           HIPCHK(hipEventElapsedTime(&xm, D->pev[PE * l + 1], D->pev[PE * l + 2]));
           HIPCHK(hipEventElapsedTime(&xp, D->pev[PE * l + 2], D->pev[PE * l + 3]));
           HIPCHK(hipEventElapsedTime(&xt, D->pev[PE * l + 3], D->pev[PE * l + 4]));
