@@ -1583,6 +1583,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   }
   auto launch_update = [&](hipStream_t stream, const UpdWork* work, int64_t cnt, double* scratch_half) {
 #ifdef SCILMM_DIAG
+    if (D->ablate == 4) return;  // timing ablation: no explicit MFMA update items at all (WRONG numbers)
     if (D->use_mfma && D->ablate == 1) {
       hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
       launches++;
@@ -1636,6 +1637,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     const Dev::CellSet& CS = D->cellset[which];
     const int64_t u0 = CS.level_ptr[l], u1 = CS.level_ptr[l + 1];
     if (u1 <= u0) return;
+#ifdef SCILMM_DIAG
+    if (D->ablate == 5) return;  // timing ablation: no cell-path updates (WRONG numbers)
+#endif
     const int64_t nshort = CS.level_short[l], nlong = (u1 - u0) - nshort;
     const int64_t nblk = (nshort + 255) / 256 + (nlong + 3) / 4;
     hipLaunchKernelGGL(k_sparse_cells, dim3((unsigned)nblk), dim3(256), 0, stream, u0, nshort, u1 - u0, (const int64_t*)CS.dst,

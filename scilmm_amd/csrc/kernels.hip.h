@@ -905,6 +905,9 @@ struct DenseWork {
 #ifndef SCILMM_DENSE_ABL
 #define SCILMM_DENSE_ABL 0  // tuning-harness ablations (csrc/tools/dense_bench.hip only): 1 no epilogue, 2 no global loads, 3 no LDS stores
 #endif
+#ifndef SCILMM_DENSE_VEC
+#define SCILMM_DENSE_VEC 1  // 16-byte staging accesses (0: the 8-byte form)
+#endif
 constexpr int DTR = 2 * TM;        // rows per dense work item
 constexpr int LDA2 = DTR + 16;     // == 16 mod 32 doubles: conflict-free b64 fragment reads
 
@@ -927,6 +930,50 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
   const int32_t mj = S.n - c0j;             // dense tail: the rows of front j are the labels c0j .. n-1
   const int32_t R0 = wk.ti0 * TM;
   const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+#if SCILMM_DENSE_VEC
+  // staging roles, 16 bytes per access: A row PAIR pa (rows 2 pa, 2 pa + 1) with k phase ka (of 4), B column pair pb
+  // with k phase kb (of 8).  Rows / columns of a panel column are contiguous, so a pair is one 16-byte global load
+  // (8-byte aligned: the leading dimension may be odd) and one ds_write_b128: half the load and store instructions.
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int NPA = KC / 4, NPB = KC / 8;
+  const int pa = tid & (DTR / 2 - 1), ka = tid >> 7;
+  const int pb = tid & (NB / 2 - 1), kb = tid >> 6;
+  const int ra_row = max(0, min(2 * pa, nrow - 2)), rb_col = max(0, min(2 * pb, wj - 2));  // clamped: unconditional loads
+  d2 ra[NPA], rb[NPB];
+  int32_t kd = wk.k0;   // descendant cursor of the chunk being loaded
+  int32_t kk0 = 0;      // first column of that chunk inside the descendant
+  int kc_ld = 0;        // depth of the chunk held in ra / rb
+  auto load_chunk = [&]() {
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    const int64_t md = S.n - c0d;
+    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
+    kc_ld = min(KC, wd - kk0);
+    if (SCILMM_DENSE_ABL != 2 || (kd == wk.k0 && kk0 == 0)) {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const double* q = Pd + (int64_t)min(ka + 4 * i, kc_ld - 1) * md + R0 + ra_row;
+        __builtin_memcpy(&ra[i], q, 16);
+      }
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        const double* q = Pd + (int64_t)min(kb + 8 * i, kc_ld - 1) * md + rb_col;
+        __builtin_memcpy(&rb[i], q, 16);
+      }
+    }
+    kk0 += KC;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+  };
+  auto store_chunk = [&](int b) {
+    double* As = Abuf + b * KC * LDA2;
+    double* Bs = Bbuf + b * KC * LDB;
+    const d2 zero = (d2){0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) *(d2*)&As[(ka + 4 * i) * LDA2 + 2 * pa] = (ka + 4 * i < kc_ld) ? ra[i] : zero;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) *(d2*)&Bs[(kb + 8 * i) * LDB + 2 * pb] = (kb + 8 * i < kc_ld) ? rb[i] : zero;
+  };
+#else
   // staging roles: A row ta with k phase ka (of 2), B column tb with k phase kb (of 4)
   constexpr int NPA = KC / 2, NPB = KC / 4;
   const int ta = tid & (DTR - 1), ka = tid >> 8;
@@ -959,6 +1006,7 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
 #pragma unroll
     for (int i = 0; i < NPB; ++i) Bs[(kb + 4 * i) * LDB + tb] = (kb + 4 * i < kc_ld) ? rb[i] : 0.0;
   };
+#endif
   // accumulators (64 doubles per lane in both forms)
   d4 acc16[NJB][2];
   double acc4[DTR / 16][4];
