@@ -258,6 +258,8 @@ def main():
 
     if rank == 0:
         K = steps
+        # (a --pmc pass of the 1M workload does not finish inside the pool's per-call limit -- counter collection
+        # serialises the 8000 launches of a factorization; the 300k pass is on file: profiles/r2_traffic_300k.json)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
@@ -309,7 +311,7 @@ def main():
                        "launches_per_factorize": prof["n_launches"] / K,
                        "symbolic_s": t_sym, "generate_s": t_gen, "first_evaluation_s": t_first,
                        "logdet": logdet_total, "solve_residual": resid},
-            "roofline": {"bound": "mfma", "kernel": "k_update2<true> (fp64 MFMA supernodal update)",
+            "roofline": {"bound": "mfma", "kernel": "fp64 MFMA supernodal update: k_dense<16> (dense tail) + k_update2<true> (explicit combos)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          # launches of consecutive levels overlap on two streams: the same flops over the time during

@@ -134,6 +134,13 @@ int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r
 /* Y = A_k X, row-major n x r (SparseCholesky.py:66,70,160,163) */
 int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y);
 
+/* BASELINE configs[4] ("fp64 factor with fp32 MFMA fronts"): bits = 32 runs the products of the dense-tail update on
+ * the fp32 matrix pipe (operands rounded to fp32 in LDS, every 16-deep chunk summed in fp32, chunks summed in fp64);
+ * everything else -- the subtraction from the panel, potrf, trsm, the solves -- stays fp64.  The factor then has a
+ * relative backward error of ~1e-7: callers refine their solves against the exact V (scilmm_spmm), as
+ * scilmm_amd.factor.Factor does.  bits = 64 (default) restores the all-fp64 path.  No counterpart in the reference. */
+int scilmm_set_front_precision(scilmm_symbolic* sym, int32_t bits);
+
 /* Haseman-Elston moments on the device (reference HE, SparseCholesky.py:192-246, REML's starting
  * point at :121): *frob = sum_ij (A_k1 o A_k2)_ij over the full symmetric matrices, *diag_dot = diag(A_k1) . diag(A_k2),
  * from the value arrays already resident in HBM (one streaming pass).  y'A_k y comes from scilmm_quadforms. */

@@ -65,7 +65,7 @@ SYMBOLS = [
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
     "scilmm_order", "scilmm_fill_count",
-    "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments",
+    "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments", "scilmm_set_front_precision",
     "scilmm_mm_read", "scilmm_mm_export", "scilmm_mm_error", "scilmm_mm_free",
 ]
 
@@ -121,6 +121,7 @@ def lib():
     L.scilmm_mm_error.restype = C.c_char_p
     L.scilmm_mm_free.argtypes = [vp]
     L.scilmm_mm_free.restype = None
+    L.scilmm_set_front_precision.argtypes = [vp, i32]
     L.scilmm_he_moments.argtypes = [vp, i32, i32, P(dbl), P(dbl)]
     L.scilmm_dist_init.argtypes = [vp, i32, i32, vp, vp, vp]
     L.scilmm_factor_sizes.argtypes = [vp, P(i64), P(i64), P(i64)]

@@ -112,6 +112,7 @@ struct Dev {
   std::vector<hipEvent_t> done_ev;      // per level: kernels of an owned chain level finished (main stream)
   // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
   bool dense_on = false;
+  int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
   int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
   DenseWork* d_dwork_e = nullptr;
   DenseWork* d_dwork_l = nullptr;
@@ -1459,6 +1460,7 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1616,7 +1618,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   const size_t sm_dense = sizeof(double) * (size_t)(2 * KC * LDA2 + 2 * KC * LDB);
   auto launch_dense = [&](hipStream_t stream, const DenseWork* dw, int64_t cnt, double* scratch_half) {
     if (cnt <= 0) return;
-    if (!D->use_mfma)
+    if (D->use_mfma && D->front_bits == 32)
+      hipLaunchKernelGGL(k_dense32, dim3((unsigned)cnt), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
+                         S.dense_first, dw, fac->L, scratch_half);
+    else if (!D->use_mfma)
       hipLaunchKernelGGL((k_dense<4, false>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
     else if (D->dense_mf == 4)
       hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
@@ -2524,6 +2529,20 @@ int scilmm_sync(scilmm_symbolic* sym) {
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out) {
   if (!sym || !sym->device || !out) return SCILMM_ERR_ARG;
   *out = ((Dev*)sym->device)->timing;
+  return SCILMM_OK;
+}
+
+int scilmm_set_front_precision(scilmm_symbolic* sym, int32_t bits) {
+  if (!sym || !sym->S || (bits != 32 && bits != 64)) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  D->front_bits = bits;
+  if (bits == 32 && !D->dense_on) {
+    sym->err = "fp32 fronts need the dense-tail path (tail narrower than 32768 columns: set SCILMM_TUNING=1 SCILMM_DENSE=1)";
+    return SCILMM_ERR_STATE;
+  }
   return SCILMM_OK;
 }
 

@@ -938,7 +938,10 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
   constexpr int NPA = KC / 4, NPB = KC / 8;
   const int pa = tid & (DTR / 2 - 1), ka = tid >> 7;
   const int pb = tid & (NB / 2 - 1), kb = tid >> 6;
-  const int ra_row = max(0, min(2 * pa, nrow - 2)), rb_col = max(0, min(2 * pb, wj - 2));  // clamped: unconditional loads
+  // a pair that starts inside the range is loaded where it is (at an odd edge its second element is the first one past
+  // the range: valid memory -- the next rows of the column, the next column, or the slack behind L -- and its LDS cell
+  // is never read back into a stored result); pairs beyond the range re-read pair 0
+  const int ra_row = 2 * pa < nrow ? 2 * pa : 0, rb_col = 2 * pb < wj ? 2 * pb : 0;
   d2 ra[NPA], rb[NPB];
   int32_t kd = wk.k0;   // descendant cursor of the chunk being loaded
   int32_t kk0 = 0;      // first column of that chunk inside the descendant
@@ -1116,6 +1119,132 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) put(16 * pr + li, 16 * wv + 4 * q4 + lk, acc4[pr][q4]);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dense32: the dense-tail update with the PRODUCTS on the fp32 matrix pipe and the SUMS in fp64 -- the
+// "fp64 factor with fp32 MFMA fronts" of BASELINE configs[4] (opt-in: scilmm_set_front_precision(sym, 32)).
+// Operands are rounded to fp32 when they are staged into LDS (the image is half as large), a 16-deep chunk is
+// multiplied with v_mfma_f32_16x16x4_f32 into fp32 accumulators, and after every chunk those are folded into the
+// fp64 accumulators that live across the whole item (so the fp32 error does not grow with K: each chunk contributes
+// a relative error of ~1e-6 of its own magnitude, the fold and everything after it -- the subtraction from the
+// panel, k_potrf, k_trsm, the solves -- is fp64).  The factor then carries a relative backward error of ~1e-7;
+// scilmm_amd.factor.Factor repairs the solves by iterative refinement against the exact V (fp64 SpMM on the device).
+// Same work items, slabs and epilogue contract as k_dense.  fp32 MFMA result layout (differs from the f64 form):
+// lane l, register r holds D[M = 4 (l >> 4) + r][N = l & 15].
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int LDA2F = DTR + 16;   // floats; == 16 mod 64: the four k rows of a fragment read hit disjoint banks
+constexpr int LDBF = NB + 16;
+
+__global__ __launch_bounds__(512, 1) void k_dense32(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, double* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  float* Abuf = (float*)smem;                 // [2][KC][LDA2F]
+  float* Bbuf = Abuf + 2 * KC * LDA2F;        // [2][KC][LDBF]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int NPA = KC / 4, NPB = KC / 8;
+  const int pa = tid & (DTR / 2 - 1), ka = tid >> 7;
+  const int pb = tid & (NB / 2 - 1), kb = tid >> 6;
+  const int ra_row = 2 * pa < nrow ? 2 * pa : 0, rb_col = 2 * pb < wj ? 2 * pb : 0;  // see k_dense
+  d2 ra[NPA], rb[NPB];
+  int32_t kd = wk.k0, kk0 = 0;
+  int kc_ld = 0;
+  auto load_chunk = [&]() {
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    const int64_t md = S.n - c0d;
+    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
+    kc_ld = min(KC, wd - kk0);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) __builtin_memcpy(&ra[i], Pd + (int64_t)min(ka + 4 * i, kc_ld - 1) * md + R0 + ra_row, 16);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) __builtin_memcpy(&rb[i], Pd + (int64_t)min(kb + 8 * i, kc_ld - 1) * md + rb_col, 16);
+    kk0 += KC;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+  };
+  auto store_chunk = [&](int b) {
+    float* As = Abuf + b * KC * LDA2F;
+    float* Bs = Bbuf + b * KC * LDBF;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const bool on = ka + 4 * i < kc_ld;
+      *(f2*)&As[(ka + 4 * i) * LDA2F + 2 * pa] = (f2){on ? (float)ra[i][0] : 0.0f, on ? (float)ra[i][1] : 0.0f};
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      const bool on = kb + 8 * i < kc_ld;
+      *(f2*)&Bs[(kb + 8 * i) * LDBF + 2 * pb] = (f2){on ? (float)rb[i][0] : 0.0f, on ? (float)rb[i][1] : 0.0f};
+    }
+  };
+  // wave wv: rows [32 wv, 32 wv + 32) x all 128 columns; fp64 accumulators across the item, fp32 ones per chunk
+  d4 acc[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) { acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  const int li = lane & 15, lk = lane >> 4;
+  if (wk.k0 >= wk.k1) return;
+  load_chunk();
+  int kc_cur = kc_ld;
+  store_chunk(0);
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    const bool more = kd < wk.k1;
+    if (more) load_chunk();
+    const float* Ac = Abuf + buf * KC * LDA2F;
+    const float* Bc = Bbuf + buf * KC * LDBF;
+    const int kc4 = (kc_cur + 3) & ~3;
+    f4 c32[NJB][2];
+#pragma unroll
+    for (int a = 0; a < NJB; ++a) { c32[a][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[a][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+    for (int k4 = 0; k4 < kc4; k4 += 4) {
+      const float a0 = Ac[(k4 + lk) * LDA2F + 32 * wv + li], a1 = Ac[(k4 + lk) * LDA2F + 32 * wv + 16 + li];
+      float b[NJB];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDBF + 16 * jb + li];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        c32[jb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[jb], a0, c32[jb][0], 0, 0, 0);
+        c32[jb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[jb], a1, c32[jb][1], 0, 0, 0);
+      }
+    }
+    // fold the chunk's fp32 sums into the fp64 accumulators
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][ib][r] += (double)c32[jb][ib][r];
+    if (!more) break;
+    store_chunk(buf ^ 1);
+    kc_cur = kc_ld;
+    __syncthreads();
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 32 * wv + 16 * ib + li, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= acc[jb][ib][r];
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = acc[jb][ib][r];
+        }
+      }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -68,22 +68,24 @@ int main(int argc, char** argv) {
   printf("T=%d panels, target %d: %zu items (%d descendants each), %.3f TFLOP per launch, %.1f MB of slabs\n", T, j, work.size(), per,
          flops / 1e12, slot * TM * NB * 8 / 1e6);
   for (int fill : {0, 1})
-  for (int mf : {16, 4}) {
+  for (int mf : {16, 4, 32}) {
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, (size_t)sn_loff[T], fill);
     for (int rep = 0; rep < 3; ++rep) {
       unsigned long long z[2] = {0, 0};
       CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dense_clk), z, sizeof(z)));
       hipEventRecord(e0);
       if (mf == 16) hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
-      else hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
+      else if (mf == 4) hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
+      else hipLaunchKernelGGL(k_dense32, dim3((unsigned)work.size()), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), 0, S, 0, d_work, L, scratch);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       CK(hipGetLastError());
       CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_dense_clk), sizeof(z)));
-      if (rep) printf("k_dense<%d>, %s operands: %.3f ms -> %.2f TFLOP/s at %.2f GHz shader clock\n", mf, fill ? "random" : "zero", ms,
+      if (rep && mf != 32) printf("k_dense<%d>, %s operands: %.3f ms -> %.2f TFLOP/s at %.2f GHz shader clock\n", mf, fill ? "random" : "zero", ms,
                       flops / ms / 1e9, 0.1 * (double)z[1] / (double)z[0]);
+      if (rep && mf == 32) printf("k_dense32 (fp32 products, fp64 sums), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
     }
   }
   return 0;

@@ -132,7 +132,7 @@ class HipChainEngine(object):
                                                             C.c_void_p(self._bufs[2].data_ptr()), C.byref(h)), self.sym._h)
         from .factor import Factor
         self.fac = Factor.__new__(Factor)
-        self.fac.sym, self.fac.n, self.fac._h = self.sym, self.sym.n, h
+        self.fac.sym, self.fac.n, self.fac._h, self.fac._s2 = self.sym, self.sym.n, h, None
         self.n = self.sym.n
 
     def factorize(self, sigma2):

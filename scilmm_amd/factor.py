@@ -50,6 +50,7 @@ class Symbolic(object):
         self._h = h
         check(st, h)
         self._uploaded = False
+        self.front_bits = 64
         if upload:
             self.upload_values()
 
@@ -111,6 +112,12 @@ class Symbolic(object):
         check(lib().scilmm_spmm(self._h, k, ptr(X2), X2.shape[1], ptr(Y)), self._h)
         return Y.reshape(X.shape)
 
+    def set_front_precision(self, bits):
+        """32: dense-tail products on the fp32 matrix pipe, sums in fp64 (BASELINE configs[4]); 64: all fp64 (default).
+        With 32 the factor has a ~1e-7 relative backward error; ``Factor.__call__`` then refines its solves."""
+        check(lib().scilmm_set_front_precision(self._h, int(bits)), self._h)
+        self.front_bits = int(bits)
+
     def set_profiling(self, on=True):
         check(lib().scilmm_set_profiling(self._h, int(bool(on))), self._h)
 
@@ -139,17 +146,20 @@ class Factor(object):
         bad = C.c_int32(-1)
         st = lib().scilmm_factorize(symbolic._h, ptr(s2), C.byref(h), C.byref(bad))
         self._h = h
+        self._s2 = s2.copy()
         check(st, symbolic._h, bad.value)
 
     def refactorize(self, sigma2):
         s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
         bad = C.c_int32(-1)
+        self._s2 = s2.copy()
         check(lib().scilmm_refactorize(self._h, ptr(s2), C.byref(bad)), self.sym._h, bad.value)
         return self
 
     def refactorize_async(self, sigma2):
         """Queue the refactorization and return; ``wait()`` (or any use of the factor) completes it."""
         s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
+        self._s2 = s2.copy()
         check(lib().scilmm_refactorize_async(self._h, ptr(s2)), self.sym._h)
         return self
 
@@ -173,9 +183,20 @@ class Factor(object):
         check(fn(self._h, ptr(B), B.shape[1], ptr(X)), self.sym._h)
         return X.reshape(b.shape)
 
+    REFINE_STEPS = 2  # iterative-refinement sweeps of a solve on a factor with fp32 fronts
+
     def __call__(self, b):
-        """factor(b) = V^{-1} b for b of shape (n,) or (n, r)."""
-        return self._rhs(lib().scilmm_solve, b)
+        """factor(b) = V^{-1} b for b of shape (n,) or (n, r).  On a factor with fp32 fronts (set_front_precision(32))
+        the solve is refined against the exact V = sum_k s2_k A_k (fp64 SpMM on the device): each sweep gains ~7 digits."""
+        x = self._rhs(lib().scilmm_solve, b)
+        if getattr(self.sym, "front_bits", 64) == 32 and getattr(self, "_s2", None) is not None:
+            b = np.asarray(b, dtype=np.float64)
+            for _ in range(self.REFINE_STEPS):
+                r = b.copy()
+                for k in range(self.sym.K):
+                    r -= self._s2[k] * self.sym.spmm(k, x)
+                x = x + self._rhs(lib().scilmm_solve, r)
+        return x
 
     def lmul(self, R):
         """(factor.L() @ R)[argsort(factor.P())] without exporting L (simulate_vector, SparseCholesky.py:50-51)."""

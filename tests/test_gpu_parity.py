@@ -336,3 +336,39 @@ def test_full_size_properties_1m():
     f.refactorize([2.0 * s2[0], 2.0 * s2[1]])                           # same handle: one 123 GB factor resident
     assert abs(f.logdet() - (ld + n * np.log(2.0))) < 1e-9 * abs(ld)    # logdet(cV) = logdet V + n log c
     assert rel_err(f(B), 0.5 * X) < 1e-10                               # (cV)^-1 b = V^-1 b / c
+
+
+def test_fp32_fronts_with_fp64_sums_and_refinement(monkeypatch):
+    """BASELINE configs[4]'s arithmetic ("fp64 factor with fp32 MFMA fronts") on a pedigree small enough for the
+    oracle: dense-tail products on the fp32 pipe, sums in fp64.  Stated tolerances: the factor agrees with the fp64
+    oracle to 1e-5 relative (fp32 operand rounding, ~6e-8 per product, amplified by the tail's depth), log-det to
+    1e-7 relative, and the REFINED solves (two sweeps against the exact V) to 1e-10 -- the fp64 bar."""
+    from oracle import oracle as O
+    monkeypatch.setenv("SCILMM_TUNING", "1")
+    monkeypatch.setenv("SCILMM_DENSE", "1")  # the tail of a 10k pedigree is narrower than the automatic threshold
+    A, _ = small_pedigree(10000, 0.01, 5)
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    s2 = [0.35, 0.65]
+    V = (s2[0] * A + s2[1] * I).tocsr()
+    sym = _engine([A, I])
+    f64 = sym.factorize(s2)
+    ld64, L64 = f64.logdet(), f64.L()
+    del f64
+    sym.set_front_precision(32)
+    f = sym.factorize(s2)
+    o = O.OracleFactor(V, f.P())
+    Lo = o.L()
+    dL = (f.L() - Lo).tocsr()
+    errL = np.abs(dL.data).max() / np.abs(Lo.data).max()
+    assert 0.0 < errL < 1e-5, errL                       # really a different (fp32-front) factor, within the stated bound
+    assert np.abs((L64 - Lo).tocsr().data).max() / np.abs(Lo.data).max() < TOL   # the fp64 path is untouched
+    assert abs(f.logdet() - o.logdet()) < 1e-7 * abs(o.logdet())
+    assert abs(ld64 - o.logdet()) < TOL * abs(o.logdet())
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, 5))
+    assert rel_err(f(B), o(B)) < TOL                      # refined solve
+    assert rel_err(V @ f(B), B) < 1e-11
+    sym.set_front_precision(64)
+    f.refactorize(s2)
+    assert abs(f.logdet() - ld64) == 0.0                  # back to the bitwise-reproducible fp64 factor
