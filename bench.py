@@ -11,7 +11,7 @@ resident in HBM when the timed region starts.  value = nnz(L) processed by all r
 The default workload is BASELINE configs[2] -- the 1M-individual pedigree the metric is quoted on (n = 828k after
 the unrelated-drop, nnz(L) = 1.5e10 = 123 GB, 1.6 PFLOP per factorization, ~40 s per step on one MI355X).  A driver
 that asks for --steps 20 --warmup 5 cannot get 25 such steps inside its time limit, so the step counts are BUDGETED
-by wall clock (--budget-s, default 470 s for the whole process): the first evaluation (which also builds the
+by wall clock (--budget-s, default 450 s for the whole process): the first evaluation (which also builds the
 device plan) is the warm-up, then as many timed steps as fit are run (at least one); the line reports the counts
 actually run as `steps` / `warmup` and the requested ones as `steps_requested` / `warmup_requested`.  Small
 workloads (--workload 100k) fit the requested counts and run them unchanged.
@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("SCILMM_BENCH_WORKLOAD", "1m"), choices=sorted(WORKLOADS))
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SCILMM_BENCH_BUDGET_S", "470")),
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SCILMM_BENCH_BUDGET_S", "450")),
                     help="wall-clock budget of the whole process; the step counts are cut to fit it (>= 1 timed step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--front-bits", type=int, default=64, choices=[32, 64],
