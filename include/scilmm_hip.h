@@ -62,6 +62,7 @@ typedef struct scilmm_info {
   double solve_flops_per_rhs; /* 4 nnz(L_stored) : forward + backward sweep per right-hand side */
   double update_flops_executed; /* update_flops plus the explicit zeros of the padded dense tail */
   int32_t dense_first;  /* fronts [dense_first, nsuper) form the dense tail (nsuper: none) */
+  double dense_flops;   /* algorithmic update flops among the fronts of the dense tail (true structure): k_dense's work */
 } scilmm_info;
 
 /* --- symbolic phase: replaces cholmod_analyze inside sk_cholesky (SparseCholesky.py:23-26), but once per
@@ -164,6 +165,9 @@ typedef struct scilmm_timing {
   /* wall time during which at least one update launch was running (early launches of consecutive levels
    * overlap on the two side streams, so update_ms -- the SUM of launch durations -- counts that time twice) */
   double update_union_ms;
+  /* the dense-tail kernel alone (k_dense / k_dense32): summed launch durations and launch count of the last factorize */
+  double dense_ms;
+  int64_t n_dense_launches;
 } scilmm_timing;
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
 /* Bracket every kernel class of the factorization with HIP events on the handle's stream (bench.py's

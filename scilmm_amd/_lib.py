@@ -45,7 +45,7 @@ class Info(C.Structure):
                 ("nnzL", C.c_int64), ("nnzL_stored", C.c_int64), ("nnz_pattern", C.c_int64),
                 ("flops", C.c_double), ("n_rows_total", C.c_int64), ("n_updates", C.c_int64),
                 ("update_flops", C.c_double), ("solve_flops_per_rhs", C.c_double),
-                ("update_flops_executed", C.c_double), ("dense_first", C.c_int32)]
+                ("update_flops_executed", C.c_double), ("dense_first", C.c_int32), ("dense_flops", C.c_double)]
 
 
 class Timing(C.Structure):
@@ -53,7 +53,7 @@ class Timing(C.Structure):
                 ("solve_bwd_ms", C.c_double), ("lmul_ms", C.c_double), ("quad_ms", C.c_double),
                 ("n_launches", C.c_int64), ("update_ms", C.c_double), ("potrf_ms", C.c_double),
                 ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64), ("reduce_cells_ms", C.c_double),
-                ("update_union_ms", C.c_double)]
+                ("update_union_ms", C.c_double), ("dense_ms", C.c_double), ("n_dense_launches", C.c_int64)]
 
 
 # every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)

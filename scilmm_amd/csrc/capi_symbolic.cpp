@@ -55,6 +55,7 @@ int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
   info->update_flops = S.update_flops - S.update_flops_pad;  // algorithmic: without the dense-tail padding
   info->update_flops_executed = S.update_flops;
   info->dense_first = S.dense_first;
+  info->dense_flops = S.dense_flops;
   info->solve_flops_per_rhs = 4.0 * (double)S.nnzL_stored;
   return SCILMM_OK;
 }

@@ -1577,7 +1577,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     if (cs) HIPCHK(hipStreamWaitEvent(cs, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
   const bool prof = D->profiling;
-  constexpr int PE = 8;  // profiling events per level
+  constexpr int PE = 12;  // profiling events per level
   if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
     size_t old = D->pev.size();
     D->pev.resize((size_t)PE * S.nlevels, nullptr);
@@ -1679,7 +1679,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 8], sd));
     launch_dense(sd, D->d_dwork_e + D->dwork_e_ptr[l], D->dwork_e_ptr[l + 1] - D->dwork_e_ptr[l], D->scratch + (size_t)sidx * half);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 9], sd));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
     if (slab_compact) HIPCHK(hipStreamWaitEvent(sd, D->chain_ev[3 * l], 0));
     {
@@ -1757,7 +1759,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         }
         if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
         if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 10], st));
         launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], D->dwork_l_ptr[l + 1] - D->dwork_l_ptr[l], sh);
+        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 11], st));
         if (D->compact_mode == 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l], sh);
         if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
         launch_reduce(st, r0, r1);
@@ -1854,7 +1858,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   const Symbolic& S = *sym->S;
   hipStream_t st = D->stream;
   const bool prof = D->profiling;
-  constexpr int PE = 8;
+  constexpr int PE = 12;
   fac->pending = false;
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(D->side));
@@ -1871,8 +1875,8 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   D->timing.factor_ms = f;
   const int32_t status = *fac->h_status;
   if (prof) {
-    double tu = 0, tp = 0, tt = 0, tmid = 0;
-    int64_t nu = 0;
+    double tu = 0, tp = 0, tt = 0, tmid = 0, td = 0;
+    int64_t nu = 0, nd = 0;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       float x = 0;
       if (D->work_ptr[l + 1] > D->work_ptr[l] || D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]) {
@@ -1884,6 +1888,16 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
         HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 5], D->pev[PE * l + 6]));
         tu += x;
         nu += (D->early_ptr[l + 1] > D->early_ptr[l]) + (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]);
+      }
+      if (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
+        HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 8], D->pev[PE * l + 9]));
+        td += x;
+        nd++;
+      }
+      if (D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]) {
+        HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 10], D->pev[PE * l + 11]));
+        td += x;
+        nd++;
       }
       HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 1], D->pev[PE * l + 2]));
       tmid += x;
@@ -1897,6 +1911,8 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
     D->timing.trsm_ms = tt;
     D->timing.reduce_cells_ms = tmid;
     D->timing.n_update_launches = nu;
+    D->timing.dense_ms = td;          // k_dense launches alone (early + late; they overlap each other on the two side streams)
+    D->timing.n_dense_launches = nd;
     {
       // union of the update launches' [start, end] intervals, measured from the end of the assembly
       std::vector<std::pair<float, float>> iv;

@@ -509,6 +509,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         }
       }
       S->update_flops_pad = -true_tail;  // completed in step 10: executed(tail) - true(tail)
+      S->dense_flops = true_tail;
       S->dense_first = best;
       S->sn_rows.resize((size_t)S->sn_rowptr[best]);
       for (int32_t q = best; q < ns; ++q) {

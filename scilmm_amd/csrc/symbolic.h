@@ -110,6 +110,7 @@ struct Symbolic {
   int64_t nnzL_stored = 0; // doubles of panel storage (includes relaxation zeros and the upper part of diagonal blocks)
   double flops = 0;        // sum colcount^2
   double update_flops = 0; // flops of all supernodal updates as EXECUTED (lower-triangular count; includes the padding of the dense tail)
+  double dense_flops = 0;       // algorithmic update flops among the dense-tail fronts (true structure)
   double update_flops_pad = 0;  // part of update_flops that is padding of the dense tail (executed - algorithmic)
   std::string error;
 };
