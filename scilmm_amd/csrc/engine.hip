@@ -111,6 +111,17 @@ struct Dev {
   hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
   std::vector<hipEvent_t> done_ev;      // per level: kernels of an owned chain level finished (main stream)
   // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
+  // prelude -> tail contributions in descendant coordinates (k_outside; fp64 atomics): one launch between the last
+  // prelude level and the first tail level
+  bool outside_on = false;
+  int32_t tail_level = 0;               // level of the first tail front
+  std::vector<uint8_t> outside_desc;    // [nsuper] descendant handled by k_outside
+  OutsideWork* d_owork = nullptr;
+  int64_t n_owork = 0;
+  int32_t* d_tail_front = nullptr;
+  uint8_t* d_keep_front = nullptr;
+  hipStream_t outside_st = nullptr;
+  hipEvent_t out_ev = nullptr;
   bool dense_on = false;
   int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
   int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
@@ -216,6 +227,8 @@ void dev_free(void* p) {
   for (auto& cs : D->cside)
     if (cs) (void)hipStreamDestroy(cs);
   if (D->rest) (void)hipStreamDestroy(D->rest);
+  if (D->outside_st) (void)hipStreamDestroy(D->outside_st);
+  if (D->out_ev) (void)hipEventDestroy(D->out_ev);
   if (D->h_chain_err) (void)hipHostFree(D->h_chain_err);
   for (auto& e : D->chain_ev)
     if (e) (void)hipEventDestroy(e);
@@ -541,9 +554,64 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* emf = tune_env("SCILMM_DENSE_MF");
     if (emf) D->dense_mf = atoi(emf) == 4 ? 4 : 16;
   }
+  {
+    // k_outside takes over the update pairs (tail target, prelude descendant below the tail's first level) unless the
+    // caller asks for the bitwise-reproducible schedule (SCILMM_DETERMINISTIC=1) or the combos were already built
+    const char* edet = getenv("SCILMM_DETERMINISTIC");
+    const char* eout = tune_env("SCILMM_OUTSIDE");
+    int st = SCILMM_OK;
+    D->outside_desc.assign((size_t)std::max(S.nsuper, 1), 0);
+    D->outside_on = S.dense_first < S.nsuper && !(edet && edet[0] == '1') && !(eout && eout[0] == '0') && !sym->S->combos_built;
+    if (D->outside_on) {
+      D->tail_level = S.sn_level[S.dense_first];
+      const int32_t c0_tail = S.sn_start[S.dense_first];
+      std::vector<OutsideWork> ow;
+      for (int32_t d = 0; d < S.dense_first; ++d) {
+        if (S.sn_level[d] >= D->tail_level) continue;  // finished too late for the one launch before the tail
+        const int32_t* rd = S.sn_rows.data() + S.sn_rowptr[d];
+        const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+        const int32_t t0 = (int32_t)(std::lower_bound(rd, rd + md, c0_tail) - rd);
+        if (t0 >= md) continue;
+        D->outside_desc[d] = 1;
+        const int32_t nb = (md - t0 + TM - 1) / TM;
+        for (int32_t bi = 0; bi < nb; ++bi)
+          for (int32_t bj = 0; bj <= bi; ++bj) ow.push_back(OutsideWork{d, t0, bi, bj});
+      }
+      D->n_owork = (int64_t)ow.size();
+      if (D->n_owork == 0 || D->tail_level == 0) {
+        D->outside_on = false;
+        std::fill(D->outside_desc.begin(), D->outside_desc.end(), 0);
+      } else {
+        // widest descendants first (their block pairs are the long items... all items are 128 x 128 x w_d: order by w_d)
+        std::stable_sort(ow.begin(), ow.end(), [&](const OutsideWork& a, const OutsideWork& b) {
+          return (S.sn_start[a.d + 1] - S.sn_start[a.d]) > (S.sn_start[b.d + 1] - S.sn_start[b.d]);
+        });
+        const OutsideWork* dow;
+        if ((st = upload(sym, D, ow, &dow)) != SCILMM_OK) return st;
+        D->d_owork = (OutsideWork*)dow;
+        std::vector<int32_t> tf((size_t)(S.n - c0_tail));
+        for (int32_t f = S.dense_first; f < S.nsuper; ++f)
+          for (int32_t c = S.sn_start[f]; c < S.sn_start[f + 1]; ++c) tf[(size_t)(c - c0_tail)] = f;
+        const int32_t* dtf;
+        if ((st = upload(sym, D, tf, &dtf)) != SCILMM_OK) return st;
+        D->d_tail_front = (int32_t*)dtf;
+        const uint8_t* dkf;
+        if ((st = upload(sym, D, D->keep_front, &dkf)) != SCILMM_OK) return st;
+        D->d_keep_front = (uint8_t*)dkf;
+        int lo4 = 0, hi4 = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo4, &hi4));
+        HIPCHK(hipStreamCreateWithPriority(&D->outside_st, hipStreamNonBlocking, hi4));
+        HIPCHK(hipEventCreateWithFlags(&D->out_ev, hipEventDisableTiming));
+        if (pverb)
+          fprintf(stderr, "[scilmm plan] k_outside: %lld block-pair items of prelude fronts below level %d (tail starts at column %d)\n",
+                  (long long)D->n_owork, D->tail_level, c0_tail);
+      }
+    }
+  }
   if (!sym->S->combos_built) {
     // (a handle analysed through scilmm_symbolic_get("combo_*") carries the full lists: then the dense path stays off)
-    scilmm::build_tile_combos(sym->S, D->world > 1 ? D->keep_front.data() : nullptr, D->dense_on);
+    scilmm::build_tile_combos(sym->S, D->world > 1 ? D->keep_front.data() : nullptr, D->dense_on,
+                              D->outside_on ? D->outside_desc.data() : nullptr);
     plap("tile combos");
   } else {
     D->dense_on = false;
@@ -630,7 +698,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       // under the saturating early updates both run ~1.6x slower than isolated.
       const char* ens = tune_env("SCILMM_SPLIT_CHAIN");
       const char* ecp = tune_env("SCILMM_COMPACT");
-      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1') && D->world == 1 && !D->dense_on;
+      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1') && D->world == 1 && !D->dense_on && S.dense_first >= S.nsuper;
       int64_t why[3] = {0, 0, 0};
       for (int32_t l = 1; allow && l + 1 < S.nlevels; ++l) {
         if (S.level_ptr[l + 1] - S.level_ptr[l] != 1 || S.level_ptr[l + 2] - S.level_ptr[l + 1] != 1) continue;
@@ -1576,6 +1644,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   for (auto& cs : D->cside)
     if (cs) HIPCHK(hipStreamWaitEvent(cs, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
+  if (D->outside_st) HIPCHK(hipStreamWaitEvent(D->outside_st, D->ev_asm, 0));
   const bool prof = D->profiling;
   constexpr int PE = 12;  // profiling events per level
   if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
@@ -1666,6 +1735,13 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     hipStream_t sd = sidx == 0 ? D->side : (sidx == 1 ? D->side2 : D->side3);
     // its youngest descendants sit look_depth + 1 levels below
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
+    // tail targets: the atomic contributions of the prelude (k_outside) must have landed before anything else
+    // reads-modifies-writes a tail panel (the event has been recorded: these launches are deferred until it is)
+    if (D->outside_on && l >= D->tail_level) {
+      HIPCHK(hipStreamWaitEvent(sd, D->out_ev, 0));
+      for (auto& cs : D->cside)
+        if (cs) HIPCHK(hipStreamWaitEvent(cs, D->out_ev, 0));
+    }
     const int64_t ncw_e = D->cearly_ptr[l + 1] - D->cearly_ptr[l];
     const bool slab_compact = D->compact_mode == 2 && ncw_e > 0 && D->cside[l & 1];
     if (slab_compact) {
@@ -1714,7 +1790,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
     return SCILMM_OK;
   };
+  // (early launches of tail levels are deferred until the k_outside launch has been queued: see below)
+  auto deferred = [&](int32_t le) -> bool { return D->outside_on && le >= D->tail_level; };
   for (int32_t l = 1; l <= D->look_depth && l < S.nlevels; ++l) {
+    if (deferred(l)) continue;
     int rc = launch_early(l);
     if (rc != SCILMM_OK) return rc;
   }
@@ -1723,10 +1802,11 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
     double* sh = D->scratch + (size_t)3 * half;
     // early(l + depth) may start as soon as level l-1 is finished: issue it before this level's own kernels
-    if (l >= 1 && l + D->look_depth < S.nlevels) {
+    if (l >= 1 && l + D->look_depth < S.nlevels && !(l < D->tail_level && deferred(l + D->look_depth))) {
       int rc = launch_early(l + D->look_depth);
       if (rc != SCILMM_OK) return rc;
     }
+    if (D->outside_on && l == D->tail_level) HIPCHK(hipStreamWaitEvent(st, D->out_ev, 0));
     const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
     const int64_t r0 = D->red_ptr[l], r1 = D->red_ptr[l + 1];
     auto launch_reduce = [&](hipStream_t stream, int64_t q0, int64_t q1) {
@@ -1840,6 +1920,24 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       HIPCHK(hipStreamWaitEvent(rs, e_t1, 0));
       HIPCHK(hipEventRecord(D->lev_ev[2 * l], rs));
     }
+    if (D->outside_on && l == D->tail_level - 1) {
+      // ---- every prelude front below the tail's first level is final: its contribution to the tail, in ITS
+      //      coordinates, with atomic subtraction (k_outside); nothing else touches a tail panel meanwhile
+      HIPCHK(hipStreamWaitEvent(D->outside_st, D->lev_ev[2 * l], 0));
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_outside<true>, dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
+                           (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+      else
+        hipLaunchKernelGGL(k_outside<false>, dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
+                           (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+      launches++;
+      HIPCHK(hipEventRecord(D->out_ev, D->outside_st));
+      for (int32_t le = D->tail_level; le <= l + D->look_depth && le < S.nlevels; ++le) {
+        if (le < 1) continue;
+        int rc = launch_early(le);
+        if (rc != SCILMM_OK) return rc;
+      }
+    }
   }
   if (D->world > 1 && S.nlevels > D->dist_l0) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (S.nlevels - 1)], 0));
   HIPCHK(hipEventRecord(D->ev[2], st));
@@ -1868,6 +1966,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   for (auto& cs : D->cside)
     if (cs) HIPCHK(hipStreamSynchronize(cs));
   if (D->world > 1 && D->comm) HIPCHK(hipStreamSynchronize(D->comm));
+  if (D->outside_st) HIPCHK(hipStreamSynchronize(D->outside_st));
   float a = 0, f = 0;
   HIPCHK(hipEventElapsedTime(&a, D->ev[0], D->ev[1]));
   HIPCHK(hipEventElapsedTime(&f, D->ev[1], D->ev[2]));

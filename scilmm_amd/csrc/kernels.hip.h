@@ -1248,6 +1248,95 @@ __global__ __launch_bounds__(512, 1) void k_dense32(DevSym S, int32_t dense_firs
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_outside: the contribution of a PRELUDE front to the dense tail, computed in the descendant's own coordinates.
+// The rows of descendant d that lie in the tail (rows t0 .. m_d of its panel) are contiguous in the panel, so the
+// products  U = L_d[t0:, :] * L_d[t0:, :]^T  are plain dense 128 x 128 x w_d block products with no padding at all
+// -- where the target-coordinate kernels spend a whole 128 x 128 x 16 chunk on a piece that typically is 42 x 32
+// (22 % of their MFMA slots useful; 17 % of a 300k / 1M factorization).  Only the DESTINATION is scattered: entry
+// (i, j) of a block belongs to row label r_i, column label r_j of the tail, whose address is arithmetic because every
+// tail panel has every later column as a row.  Several descendants hit the same cells, so the subtraction is an fp64
+// atomic add (global_atomic_add_f64, no return): the sum order -- hence the last bits -- is not reproducible from run
+// to run; SCILMM_DETERMINISTIC=1 keeps these updates on the target-coordinate path (fixed order).
+// One workgroup (4 waves, wave = 32 rows x 128 columns) per lower block pair (bi >= bj) of one descendant; the
+// launch runs while nothing else touches the tail panels (after the last prelude level, before the first tail level).
+struct OutsideWork {
+  int32_t d;        // descendant front (below the dense tail)
+  int32_t t0;       // first row of its panel that lies in the tail
+  int32_t bi, bj;   // 128-row blocks of those rows: target rows / target columns
+};
+
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_outside(DevSym S, int32_t dense_first, const OutsideWork* __restrict__ work,
+                                                 const int32_t* __restrict__ tail_front,  // tail column (label - c0_tail) -> front
+                                                 const uint8_t* __restrict__ keep_front,  // multi-GPU: fronts this rank computes
+                                                 double* __restrict__ L) {
+  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];  // [k][target-row entry]
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];  // [k][target-column entry]
+  __shared__ int32_t lab_i[TM], lab_j[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const OutsideWork wk = work[blockIdx.x];
+  const int32_t d = wk.d;
+  const int32_t wd = S.sn_start[d + 1] - S.sn_start[d];
+  const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+  const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
+  const double* Pd = L + S.sn_loff[d];
+  const int32_t ri0 = wk.t0 + TM * wk.bi, rj0 = wk.t0 + NB * wk.bj;  // first panel row of the two blocks
+  const int32_t ni = min(TM, md - ri0), nj = min(NB, md - rj0);
+  if (tid < TM) lab_i[tid] = tid < ni ? rd[ri0 + tid] : -1;
+  else if (tid < TM + NB) lab_j[tid - TM] = (tid - TM) < nj ? rd[rj0 + tid - TM] : -1;
+  d4 acc[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) { acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  // staging: thread (x = tid & 127, kk = tid >> 7) carries k = kk, kk + 2, ... of row x of both blocks
+  const int x = tid & 127, kk = tid >> 7;
+  const double* pa = Pd + ri0 + min(x, ni - 1);
+  const double* pb = Pd + rj0 + min(x, nj - 1);
+  for (int32_t k0 = 0; k0 < wd; k0 += KCS) {
+    const int kc = min(KCS, wd - k0);
+    const int kc4 = (kc + 3) & ~3;
+    double va[KCS / 2], vb[KCS / 2];
+#pragma unroll
+    for (int i = 0; i < KCS / 2; ++i) {
+      const int64_t kq = k0 + min(kk + 2 * i, kc - 1);
+      va[i] = pa[kq * md];
+      vb[i] = pb[kq * md];
+    }
+    if (k0 > 0) __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+    for (int i = 0; i < KCS / 2; ++i) {
+      const int k = kk + 2 * i;
+      if (k < kc4) {
+        As[k * LDA + x] = (x < ni && k < kc) ? va[i] : 0.0;
+        Bs[k * LDB + x] = (x < nj && k < kc) ? vb[i] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (32 * wv < ni) tile_mma<MFMA>(As, Bs, kc4, NJB, lane, wv, acc);
+  }
+  // scatter: acc[jb][ib][r] = U(i, j) with i = 32 wv + 16 ib + (lane & 15), j = 16 jb + (lane >> 4) + 4 r
+  const int li = lane & 15, lr = lane >> 4;
+  const int32_t c0_tail = S.sn_start[dense_first];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jloc = 16 * jb + lr + 4 * r;
+      const int32_t cj = lab_j[jloc];
+      if (cj < 0) continue;
+      const int32_t f = tail_front[cj - c0_tail];
+      if (!keep_front[f]) continue;
+      const int32_t c0f = S.sn_start[f];
+      double* col = L + S.sn_loff[f] + (int64_t)(cj - c0f) * (S.n - c0f) - c0f;  // + row label = the cell
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        const int iloc = 32 * wv + 16 * ib + li;
+        const int32_t ci = lab_i[iloc];
+        if (ci >= cj) unsafeAtomicAdd(col + ci, -acc[jb][ib][r]);  // lower triangle only (ci = -1 for padding rows)
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Compact path of the supernodal update: combos whose rows / columns are scattered over the target tile
 // (a family subtree updating a few dozen of the 128 x 128 cells' rows and columns) would keep all eight
 // waves and all column blocks of k_update busy although only ceil(nt/16) x ceil(nq/16) blocks carry data.

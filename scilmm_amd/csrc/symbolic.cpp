@@ -745,7 +745,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 // Step 11b, on demand: for every 128-row tile of every target panel the list of descendant row ranges ("combos")
 // that land in it.  keep_front (optional, [nsuper]) restricts the enumeration to the targets a rank owns in a
 // multi-GPU run; the lists of the other tiles stay empty.
-void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense) {
+void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense, const uint8_t* skip_desc) {
   const int32_t ns = S->nsuper;
   const int32_t TM = S->tile_rows;
   const int64_t nt = S->tile_base[ns];
@@ -771,6 +771,7 @@ void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense) 
         for (int64_t e = S->upd_ptr[s]; e < S->upd_ptr[s + 1]; ++e) {
           int32_t d = S->upd_src[e];
           if (skip_dense && s >= S->dense_first && d >= S->dense_first) continue;
+          if (skip_desc && s >= S->dense_first && skip_desc[d]) continue;
           const int32_t* rd = S->sn_rows.data() + S->sn_rowptr[d];
           int32_t md = (int32_t)(S->sn_rowptr[d + 1] - S->sn_rowptr[d]);
           int32_t t = S->upd_p0[e];

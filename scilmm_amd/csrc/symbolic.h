@@ -124,6 +124,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 // tiles are enumerated (multi-GPU: the targets this rank owns); NULL = all.
 // skip_dense: leave out the update pairs whose target AND descendant lie in the dense tail (the engine handles those
 // with implicit, descriptor-free work items).
-void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense = false);
+// skip_desc (optional, [nsuper]): descendants whose contributions to dense-tail targets are computed elsewhere (k_outside).
+void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense = false, const uint8_t* skip_desc = nullptr);
 
 }  // namespace scilmm
