@@ -561,7 +561,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* eout = tune_env("SCILMM_OUTSIDE");
     int st = SCILMM_OK;
     D->outside_desc.assign((size_t)std::max(S.nsuper, 1), 0);
-    D->outside_on = S.dense_first < S.nsuper && !(edet && edet[0] == '1') && !(eout && eout[0] == '0') && !sym->S->combos_built;
+    // (like k_dense it pays from a wide tail on: at the 100k config the serial launch between prelude and tail costs
+    // 3 ms of a 66 ms factorization, at 300k it saves 120 of 1800 ms -- SCILMM_OUTSIDE=1 / 0 forces it)
+    const int32_t tail_w2 = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
+    D->outside_on = S.dense_first < S.nsuper && !(edet && edet[0] == '1') && !sym->S->combos_built &&
+                    (eout ? eout[0] != '0' : tail_w2 >= 32768);
     if (D->outside_on) {
       D->tail_level = S.sn_level[S.dense_first];
       const int32_t c0_tail = S.sn_start[S.dense_first];
