@@ -196,8 +196,78 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     if (verbose) fprintf(stderr, "[scilmm symbolic] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - tlast).count());
     tlast = now;
   };
-  // ---------------------------------------------------------------- 1. union lower pattern (original labels, by row)
+  // ---------------------------------------------------------------- 1. symmetric adjacency of the union pattern
+  // G = the union pattern without its diagonal, both halves, lists ascending: every later step of the analysis (the
+  // ordering, the elimination tree, the permuted pattern) reads it by vertex, with no scatter pass of its own.
   S->is_diag.assign(K, 1);
+  for (int32_t k = 0; k < K; ++k) {
+    bool diag = true;
+    for (int32_t i = 0; i < n && diag; ++i)
+      for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
+        if (indices[k][e] != i) { diag = false; break; }
+    S->is_diag[k] = diag ? 1 : 0;
+  }
+  std::vector<int64_t> gptr(n + 1, 0);
+  std::vector<int32_t> gidx;
+  // Fast path, inputs stored with both halves (what SciPy hands over): row i of G is the merged row i of the inputs,
+  // one pass over the rows on all cores.  Structural symmetry is verified by comparing an order-independent 64-bit
+  // hash sum of the lower entries (i, j) with that of the mirrored upper entries; inputs that store one half only, or
+  // unsymmetric ones, take the scatter path below, which reads the lower half alone.
+  bool have_g = false;
+  {
+    std::vector<int64_t> ub(n + 1, 0);
+    for (int32_t i = 0; i < n; ++i) {
+      int64_t len = 0;
+      for (int32_t k = 0; k < K; ++k) len += indptr[k][i + 1] - indptr[k][i];
+      ub[i + 1] = ub[i] + len;
+    }
+    std::vector<int32_t> stage(ub[n]);
+    std::vector<int32_t> cnt(n), low(n);
+    uint64_t hlo = 0, hup = 0;
+    auto mix = [](uint64_t x) {
+      x += 0x9e3779b97f4a7c15ull;
+      x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+      x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+      return x ^ (x >> 31);
+    };
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : hlo, hup)
+    for (int32_t i = 0; i < n; ++i) {
+      int32_t* r = stage.data() + ub[i];
+      int64_t m = 0;
+      for (int32_t k = 0; k < K; ++k)
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+          const int32_t j = indices[k][e];
+          if (j >= 0 && j < n && j != i) r[m++] = j;
+        }
+      bool sorted = true;
+      for (int64_t t = 1; t < m; ++t)
+        if (r[t - 1] >= r[t]) { sorted = false; break; }
+      if (!sorted) {
+        std::sort(r, r + m);
+        m = std::unique(r, r + m) - r;
+      }
+      int32_t lo = 0;
+      for (int64_t t = 0; t < m; ++t) {
+        const uint32_t j = (uint32_t)r[t];
+        if (r[t] < i) { hlo += mix(((uint64_t)(uint32_t)i << 32) | j); ++lo; }
+        else hup += mix(((uint64_t)j << 32) | (uint32_t)i);
+      }
+      cnt[i] = (int32_t)m;
+      low[i] = lo;
+    }
+    int64_t nlow = 0, nall = 0;
+    for (int32_t i = 0; i < n; ++i) { nlow += low[i]; nall += cnt[i]; }
+    if (hlo == hup && nall == 2 * nlow) {
+      for (int32_t i = 0; i < n; ++i) gptr[i + 1] = gptr[i] + cnt[i];
+      gidx.resize(gptr[n]);
+#pragma omp parallel for schedule(dynamic, 4096)
+      for (int32_t i = 0; i < n; ++i) std::copy(stage.data() + ub[i], stage.data() + ub[i] + cnt[i], gidx.begin() + gptr[i]);
+      S->nnz_pattern = nlow + n;
+      have_g = true;
+    }
+  }
+  if (verbose) fprintf(stderr, "[scilmm symbolic] inputs %s\n", have_g ? "store both halves: adjacency read row by row" : "do not store both halves symmetrically: lower half scattered");
+  if (!have_g) {
   std::vector<int64_t> uptr(n + 1, 0);
   std::vector<int32_t> uidx;
   {
@@ -231,18 +301,43 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
       std::copy(tmp.begin(), tmp.end(), uidx.begin() + uptr[i]);
     }
-    for (int32_t k = 0; k < K; ++k) {
-      bool diag = true;
-      for (int32_t i = 0; i < n && diag; ++i)
-        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e)
-          if (indices[k][e] != i) { diag = false; break; }
-      S->is_diag[k] = diag ? 1 : 0;
-    }
   }
   S->nnz_pattern = uptr[n];
 
-  lap("union pattern");
-  // ---------------------------------------------------------------- 2. ordering
+  // G = the union pattern without its diagonal, both halves, lists ascending: every later step of the analysis (the
+  // ordering, the elimination tree, the permuted pattern) reads it by vertex, with no scatter pass of its own.
+  // Built on all cores: the lower half of a vertex is its own row; the upper half is counted and filled with relaxed
+  // atomics and then sorted, so the result does not depend on the thread schedule.
+  {
+    std::vector<int64_t> up(n, 0);
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
+        const int32_t j = uidx[e];
+        if (j != i) __atomic_fetch_add(&up[j], 1, __ATOMIC_RELAXED);
+      }
+    for (int32_t i = 0; i < n; ++i) gptr[i + 1] = gptr[i] + (uptr[i + 1] - uptr[i] - 1) + up[i];
+    gidx.resize(gptr[n]);
+    std::vector<int64_t> fill(n);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int32_t i = 0; i < n; ++i) {
+      int64_t f = gptr[i];
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e)
+        if (uidx[e] != i) gidx[f++] = uidx[e];
+      fill[i] = f;
+    }
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
+    for (int32_t i = 0; i < n; ++i)
+      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
+        const int32_t j = uidx[e];
+        if (j != i) gidx[__atomic_fetch_add(&fill[j], 1, __ATOMIC_RELAXED)] = i;
+      }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < n; ++i) std::sort(gidx.begin() + (gptr[i + 1] - up[i]), gidx.begin() + gptr[i + 1]);
+    std::vector<int32_t>().swap(uidx);
+  }
+  }
+  lap("symmetric adjacency");
   std::vector<int32_t> perm(n);
   if (opts.ordering == 2) {
     if (!perm_in) { S->error = "user ordering requested but no permutation given"; return S; }
@@ -255,87 +350,50 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     }
   } else if (opts.ordering == 1) {
     std::iota(perm.begin(), perm.end(), 0);
-  } else {
-    // symmetric adjacency without the diagonal
-    std::vector<int64_t> gptr(n + 1, 0);
-    for (int32_t i = 0; i < n; ++i)
-      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
-        int32_t j = uidx[e];
-        if (j == i) continue;
-        gptr[i + 1]++;
-        gptr[j + 1]++;
-      }
-    for (int32_t i = 0; i < n; ++i) gptr[i + 1] += gptr[i];
-    std::vector<int32_t> gidx(gptr[n]);
-    std::vector<int64_t> fill(gptr.begin(), gptr.end() - 1);
-    for (int32_t i = 0; i < n; ++i)
-      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
-        int32_t j = uidx[e];
-        if (j == i) continue;
-        gidx[fill[i]++] = j;
-        gidx[fill[j]++] = i;
-      }
-    if (opts.ordering == 3 || opts.ordering == 4) {
-      NdOptions ndo;
-      ndo.oksep = opts.nd_oksep;
-      NdStats nds;
-      nd_order(n, gptr.data(), gidx.data(), perm.data(), ndo, &nds);
-      if (verbose)
-        fprintf(stderr, "[scilmm symbolic] nested dissection: %d -> %d compressed vertices, %lld separators, largest %lld\n", n,
-                nds.n_compressed, (long long)nds.n_separators, (long long)nds.top_separator);
-      if (opts.ordering == 4) {
-        // keep whichever ordering gives fewer factor flops (elimination tree + column counts only: cheap)
-        std::vector<int32_t> p2(n);
-        amd_order(n, gptr.data(), gidx.data(), p2.data(), opts.amd_dense);
-        double f_nd = 0, f_amd = 0;
-        fill_count(n, gptr.data(), gidx.data(), perm.data(), nullptr, &f_nd, nullptr, nullptr);
-        fill_count(n, gptr.data(), gidx.data(), p2.data(), nullptr, &f_amd, nullptr, nullptr);
-        if (verbose) fprintf(stderr, "[scilmm symbolic] factor flops: nested dissection %.4g, minimum degree %.4g\n", f_nd, f_amd);
-        if (f_amd < f_nd) perm.swap(p2);
-      }
-    } else {
-      amd_order(n, gptr.data(), gidx.data(), perm.data(), opts.amd_dense);
+  } else if (opts.ordering == 3 || opts.ordering == 4) {
+    NdOptions ndo;
+    ndo.oksep = opts.nd_oksep;
+    NdStats nds;
+    nd_order(n, gptr.data(), gidx.data(), perm.data(), ndo, &nds);
+    if (verbose)
+      fprintf(stderr, "[scilmm symbolic] nested dissection: %d -> %d compressed vertices, %lld separators, largest %lld\n", n,
+              nds.n_compressed, (long long)nds.n_separators, (long long)nds.top_separator);
+    if (opts.ordering == 4) {
+      // keep whichever ordering gives fewer factor flops (elimination tree + column counts only: cheap)
+      std::vector<int32_t> p2(n);
+      amd_order(n, gptr.data(), gidx.data(), p2.data(), opts.amd_dense);
+      double f_nd = 0, f_amd = 0;
+      fill_count(n, gptr.data(), gidx.data(), perm.data(), nullptr, &f_nd, nullptr, nullptr);
+      fill_count(n, gptr.data(), gidx.data(), p2.data(), nullptr, &f_amd, nullptr, nullptr);
+      if (verbose) fprintf(stderr, "[scilmm symbolic] factor flops: nested dissection %.4g, minimum degree %.4g\n", f_nd, f_amd);
+      if (f_amd < f_nd) perm.swap(p2);
     }
+  } else {
+    amd_order(n, gptr.data(), gidx.data(), perm.data(), opts.amd_dense);
   }
   std::vector<int32_t> iperm(n);
   for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
 
   lap("ordering");
-  // ---------------------------------------------------------------- 3. permuted strict-lower pattern by column
-  auto build_csc = [&](const std::vector<int32_t>& ip, std::vector<int64_t>& cptr, std::vector<int32_t>& cidx) {
-    // count / fill on all host cores (relaxed atomics; the per-column sort below makes the result deterministic)
-    cptr.assign(n + 1, 0);
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
-    for (int32_t i = 0; i < n; ++i)
-      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
-        int32_t j = uidx[e];
-        if (j == i) continue;
-        int32_t a = ip[i], b = ip[j];
-        __atomic_fetch_add(&cptr[std::min(a, b) + 1], 1, __ATOMIC_RELAXED);
+  // ---------------------------------------------------------------- 3. etree + postorder straight from G
+  // Liu's algorithm walks the rows of the permuted matrix in order; row i' is vertex perm[i'] and its entries left of
+  // the diagonal are the neighbours with a smaller new label -- no permuted copy of the pattern is needed for it.
+  std::vector<int32_t> parent(n, -1);
+  {
+    std::vector<int32_t> anc(n, -1);
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t v = perm[i];
+      for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
+        int32_t k = iperm[gidx[e]];
+        while (k != -1 && k < i) {
+          const int32_t nx = anc[k];
+          anc[k] = i;
+          if (nx == -1) parent[k] = i;
+          k = nx;
+        }
       }
-    for (int32_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
-    cidx.resize(cptr[n]);
-    std::vector<int64_t> fill(cptr.begin(), cptr.end() - 1);
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
-    for (int32_t i = 0; i < n; ++i)
-      for (int64_t e = uptr[i]; e < uptr[i + 1]; ++e) {
-        int32_t j = uidx[e];
-        if (j == i) continue;
-        int32_t a = ip[i], b = ip[j];
-        cidx[__atomic_fetch_add(&fill[std::min(a, b)], 1, __ATOMIC_RELAXED)] = std::max(a, b);
-      }
-#pragma omp parallel for schedule(dynamic, 1024)
-    for (int32_t j = 0; j < n; ++j) std::sort(cidx.begin() + cptr[j], cidx.begin() + cptr[j + 1]);
-  };
-  std::vector<int64_t> cptr, rptr;
-  std::vector<int32_t> cidx, ridx;
-  build_csc(iperm, cptr, cidx);
-  transpose_pattern(n, cptr, cidx, rptr, ridx);
-
-  lap("permute pattern");
-  // ---------------------------------------------------------------- 4. etree + postorder, relabel
-  std::vector<int32_t> parent;
-  etree(n, rptr, ridx, parent);
+    }
+  }
   std::vector<int32_t> post;
   postorder(n, parent, post);
   // A user-supplied permutation is honoured exactly (parity with an oracle factor of the same P);
@@ -351,10 +409,36 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     parent.swap(par2);
     perm.swap(perm2);
     for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
-    build_csc(iperm, cptr, cidx);
-    transpose_pattern(n, cptr, cidx, rptr, ridx);
     std::iota(post.begin(), post.end(), 0);
   }
+  lap("etree+postorder");
+  // ---------------------------------------------------------------- 4. permuted strict-lower pattern by column
+  // column c = vertex perm[c]; its rows are the neighbours with a larger new label, sorted (column by column, no scatter)
+  std::vector<int64_t> cptr(n + 1, 0);
+  std::vector<int32_t> cidx;
+  {
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t c = 0; c < n; ++c) {
+      const int32_t v = perm[c];
+      int64_t cnt = 0;
+      for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) cnt += iperm[gidx[e]] > c;
+      cptr[c + 1] = cnt;
+    }
+    for (int32_t c = 0; c < n; ++c) cptr[c + 1] += cptr[c];
+    cidx.resize(cptr[n]);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t c = 0; c < n; ++c) {
+      const int32_t v = perm[c];
+      int64_t f = cptr[c];
+      for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
+        const int32_t r = iperm[gidx[e]];
+        if (r > c) cidx[f++] = r;
+      }
+      std::sort(cidx.begin() + cptr[c], cidx.begin() + cptr[c + 1]);
+    }
+    std::vector<int32_t>().swap(gidx);
+  }
+  lap("permuted pattern");
   S->perm = perm;
   S->iperm = iperm;
   S->parent = parent;
@@ -436,21 +520,32 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   S->sn_rowptr.assign(ns + 1, 0);
   S->sn_parent.assign(ns, -1);
   {
-    // children lists are discovered on the fly: a child always precedes its parent
+    // rows contributed by the input pattern itself (the columns of A inside the front), on all cores; what is left
+    // for the sequential sweep below is the merge of the children's row lists (a child always precedes its parent)
+    std::vector<std::vector<int32_t>> arows(ns);
+#pragma omp parallel
+    {
+      std::vector<int32_t> mk(n, -1);
+#pragma omp for schedule(dynamic, 64)
+      for (int32_t s = 0; s < ns; ++s) {
+        const int32_t c0 = out[s].start, c1 = out[s].end;
+        std::vector<int32_t>& a = arows[s];
+        for (int32_t j = c0; j < c1; ++j)
+          for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+            const int32_t i = cidx[e];
+            if (i >= c1 && mk[i] != s) { mk[i] = s; a.push_back(i); }
+          }
+      }
+    }
     std::vector<int32_t> chead(ns, -1), cnext(ns, -1);
     std::vector<int32_t> mark(n, -1);
     std::vector<int32_t> tmp;
     S->sn_rows.reserve((size_t)(S->nnzL / 4 + n));
     for (int32_t s = 0; s < ns; ++s) {
       int32_t c0 = out[s].start, c1 = out[s].end;
-      tmp.clear();
-      for (int32_t j = c0; j < c1; ++j) {
-        mark[j] = s;
-        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
-          int32_t i = cidx[e];
-          if (i >= c1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
-        }
-      }
+      tmp.swap(arows[s]);
+      std::vector<int32_t>().swap(arows[s]);
+      for (int32_t i : tmp) mark[i] = s;
       for (int32_t c = chead[s]; c != -1; c = cnext[c]) {
         int64_t b = S->sn_rowptr[c], e2 = S->sn_rowptr[c + 1];
         int32_t wc = out[c].end - out[c].start;
@@ -469,6 +564,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
         cnext[s] = chead[p];
         chead[p] = s;
       }
+      tmp.clear();
     }
   }
   // ---------------------------------------------------------------- 7b. dense tail
@@ -559,6 +655,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     S->diag_dst.resize(n);
     S->pat_colptr = slot_ptr;
     S->pat_row.resize(slot_ptr[n]);
+#pragma omp parallel for schedule(dynamic, 4096)
     for (int32_t j = 0; j < n; ++j) {
       int64_t sl = slot_ptr[j];
       S->pat_row[sl++] = j;
@@ -569,20 +666,31 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       int64_t w = out[s].end - out[s].start;
       S->inv_off[s + 1] = S->inv_off[s] + ((w * w + 1) & ~(int64_t)1);
     }
-    std::vector<int32_t> pos(n, -1);
-    for (int32_t s = 0; s < ns; ++s) {
-      int64_t rb = S->sn_rowptr[s], re = S->sn_rowptr[s + 1];
-      int64_t m = re - rb;
-      for (int64_t t = rb; t < re; ++t) pos[S->sn_rows[t]] = (int32_t)(t - rb);
-      for (int32_t j = out[s].start; j < out[s].end; ++j) {
-        int64_t colbase = S->sn_loff[s] + (int64_t)(j - out[s].start) * m;
-        int64_t sl = slot_ptr[j];
-        S->asm_dst[sl] = colbase + (j - out[s].start);
-        S->diag_dst[j] = S->asm_dst[sl];
-        ++sl;
-        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) S->asm_dst[sl++] = colbase + pos[cidx[e]];
+#pragma omp parallel
+    {
+      std::vector<int32_t> pos(n, -1);
+#pragma omp for schedule(dynamic, 16)
+      for (int32_t s = 0; s < ns; ++s) {
+        int64_t rb = S->sn_rowptr[s], re = S->sn_rowptr[s + 1];
+        int64_t m = re - rb;
+        const bool tail = s >= S->dense_first;  // rows = every column from the front's first on
+        const int32_t c0 = out[s].start;
+        if (!tail)
+          for (int64_t t = rb; t < re; ++t) pos[S->sn_rows[t]] = (int32_t)(t - rb);
+        for (int32_t j = c0; j < out[s].end; ++j) {
+          int64_t colbase = S->sn_loff[s] + (int64_t)(j - c0) * m;
+          int64_t sl = slot_ptr[j];
+          S->asm_dst[sl] = colbase + (j - c0);
+          S->diag_dst[j] = S->asm_dst[sl];
+          ++sl;
+          if (tail)
+            for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) S->asm_dst[sl++] = colbase + (cidx[e] - c0);
+          else
+            for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) S->asm_dst[sl++] = colbase + pos[cidx[e]];
+        }
       }
     }
+    lap("  pattern slots -> panels");
     // per input matrix: where does each stored lower entry go
     S->val_slot.resize(K);
     S->val_src.resize(K);
@@ -625,6 +733,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       }
       S->val_slot[k].resize(cntk);
       S->val_src[k].resize(cntk);
+      lap("  bucket entries by column");
 #pragma omp parallel
       {
         std::vector<std::pair<int32_t, int64_t>> tmp;
@@ -654,7 +763,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     }
     S->nnz_pattern = slot_ptr[n];
   }
-  lap("assembly maps");
+  lap("  sort / merge buckets");
   // ---------------------------------------------------------------- 10. left-looking update schedule
   {
     S->upd_ptr.assign(ns + 1, 0);

@@ -138,3 +138,21 @@ def test_dense_tail_is_a_padded_chain():
     for s in range(df):  # everything below the tail is untouched
         assert np.array_equal(rows[rp[s]:rp[s + 1]], rrows[rrp[s]:rrp[s + 1]])
     assert sym.info().nnzL == ref.info().nnzL  # the algorithmic count does not include the padding
+
+
+def test_lower_only_and_full_inputs_give_the_same_analysis():
+    """Inputs that store both halves take the row-by-row adjacency path, inputs that store the lower half only (or an
+    unsymmetric pattern, whose upper entries are ignored) the scatter path: same permutation, same structure, same
+    assembly maps modulo the position of the stored entries."""
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(3000, 0.01, 2)
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    full = Symbolic([A, I], upload=False)
+    lower = Symbolic([sp.tril(A, format="csr"), I], upload=False)
+    junk = sp.tril(A, format="csr") + sp.triu(sp.random(n, n, 0.001, random_state=1, format="csr"), 1)
+    uns = Symbolic([junk.tocsr(), I], upload=False)
+    for other in (lower, uns):
+        for key in ("perm", "colcount", "sn_start", "sn_rowptr", "sn_rows", "sn_parent", "sn_level"):
+            assert np.array_equal(full.get(key), other.get(key)), key
+        assert full.info().nnzL == other.info().nnzL and full.info().nnz_pattern == other.info().nnz_pattern
