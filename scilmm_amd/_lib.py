@@ -158,7 +158,7 @@ _GET_DTYPES = {"sn_rowptr": np.int64, "sn_loff": np.int64, "asm_dst": np.int64, 
 def symbolic_get(sym, name):
     n = C.c_int64(0)
     check(lib().scilmm_symbolic_get(sym, name.encode(), None, C.byref(n)), sym)
-    out = np.empty(n.value, dtype=_GET_DTYPES.get(name, np.int32))
+    out = np.empty(n.value, dtype=np.int64 if name.startswith("val_") else _GET_DTYPES.get(name, np.int32))
     check(lib().scilmm_symbolic_get(sym, name.encode(), ptr(out), C.byref(n)), sym)
     return out
 

@@ -1,4 +1,5 @@
 // C-ABI entry points for the host-side symbolic phase (no GPU needed). Declared in include/scilmm_hip.h.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,6 +75,16 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
   if (!std::strcmp(what, "dense_first")) {
     if (out) *(int32_t*)out = S.dense_first;
     *count = 1;
+    return SCILMM_OK;
+  }
+  // value-assembly maps of input matrix k: "val_slot:k" / "val_src:k" (pattern slot <- index into data_k)
+  if (!std::strncmp(what, "val_slot:", 9) || !std::strncmp(what, "val_src:", 8)) {
+    const bool slot = what[4] == 's' && what[5] == 'l';
+    const int k = std::atoi(what + (slot ? 9 : 8));
+    if (k < 0 || k >= S.K) return SCILMM_ERR_ARG;
+    const std::vector<int64_t>& v = slot ? S.val_slot[k] : S.val_src[k];
+    if (out) std::memcpy(out, v.data(), v.size() * sizeof(int64_t));
+    *count = (int64_t)v.size();
     return SCILMM_OK;
   }
   GET("perm", perm)

@@ -378,18 +378,43 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   // ---------------------------------------------------------------- 3. etree + postorder straight from G
   // Liu's algorithm walks the rows of the permuted matrix in order; row i' is vertex perm[i'] and its entries left of
   // the diagonal are the neighbours with a smaller new label -- no permuted copy of the pattern is needed for it.
+  // The neighbour lists are filtered (smaller new label only) and relabelled on all cores, a block of rows at a time;
+  // the sequential part reads the result as a stream.  nlarger[v] = neighbours with a larger label: the size of v's
+  // column in the permuted pattern (unchanged by the postorder below -- adjacent vertices are ancestor and descendant).
   std::vector<int32_t> parent(n, -1);
+  std::vector<int32_t> nlarger(n);
   {
     std::vector<int32_t> anc(n, -1);
-    for (int32_t i = 0; i < n; ++i) {
-      const int32_t v = perm[i];
-      for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
-        int32_t k = iperm[gidx[e]];
-        while (k != -1 && k < i) {
-          const int32_t nx = anc[k];
-          anc[k] = i;
-          if (nx == -1) parent[k] = i;
-          k = nx;
+    constexpr int32_t BLK = 16384;
+    std::vector<int32_t> buf, bcnt(BLK);
+    std::vector<int64_t> boff(BLK + 1);
+    for (int32_t i0 = 0; i0 < n; i0 += BLK) {
+      const int32_t i1 = std::min(n, i0 + BLK);
+      boff[0] = 0;
+      for (int32_t i = i0; i < i1; ++i) boff[i - i0 + 1] = boff[i - i0] + (gptr[perm[i] + 1] - gptr[perm[i]]);
+      if ((int64_t)buf.size() < boff[i1 - i0]) buf.resize(boff[i1 - i0]);
+#pragma omp parallel for schedule(dynamic, 64)
+      for (int32_t i = i0; i < i1; ++i) {
+        const int32_t v = perm[i];
+        int32_t* o = buf.data() + boff[i - i0];
+        int32_t m = 0;
+        for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
+          const int32_t k = iperm[gidx[e]];
+          if (k < i) o[m++] = k;
+        }
+        bcnt[i - i0] = m;
+        nlarger[v] = (int32_t)(gptr[v + 1] - gptr[v]) - m;
+      }
+      for (int32_t i = i0; i < i1; ++i) {
+        const int32_t* o = buf.data() + boff[i - i0];
+        for (int32_t t = 0; t < bcnt[i - i0]; ++t) {
+          int32_t k = o[t];
+          while (k != -1 && k < i) {
+            const int32_t nx = anc[k];
+            anc[k] = i;
+            if (nx == -1) parent[k] = i;
+            k = nx;
+          }
         }
       }
     }
@@ -417,14 +442,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   std::vector<int64_t> cptr(n + 1, 0);
   std::vector<int32_t> cidx;
   {
-#pragma omp parallel for schedule(dynamic, 1024)
-    for (int32_t c = 0; c < n; ++c) {
-      const int32_t v = perm[c];
-      int64_t cnt = 0;
-      for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) cnt += iperm[gidx[e]] > c;
-      cptr[c + 1] = cnt;
-    }
-    for (int32_t c = 0; c < n; ++c) cptr[c + 1] += cptr[c];
+    for (int32_t c = 0; c < n; ++c) cptr[c + 1] = cptr[c] + nlarger[perm[c]];
     cidx.resize(cptr[n]);
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int32_t c = 0; c < n; ++c) {
@@ -554,12 +572,19 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
           if (i >= c1 && mark[i] != s) { mark[i] = s; tmp.push_back(i); }
         }
       }
-      std::sort(tmp.begin(), tmp.end());
       for (int32_t j = c0; j < c1; ++j) S->sn_rows.push_back(j);
-      S->sn_rows.insert(S->sn_rows.end(), tmp.begin(), tmp.end());
+      const size_t first = S->sn_rows.size();
+      if ((int64_t)tmp.size() * 16 > (int64_t)(n - c1)) {
+        // long list (the fronts of the trailing clique hold most of the later columns): read it off the marks
+        for (int32_t i = c1; i < n; ++i)
+          if (mark[i] == s) S->sn_rows.push_back(i);
+      } else {
+        std::sort(tmp.begin(), tmp.end());
+        S->sn_rows.insert(S->sn_rows.end(), tmp.begin(), tmp.end());
+      }
       S->sn_rowptr[s + 1] = (int64_t)S->sn_rows.size();
       if (!tmp.empty()) {
-        int32_t p = snode_of[tmp[0]];
+        int32_t p = snode_of[S->sn_rows[first]];
         S->sn_parent[s] = p;
         cnext[s] = chead[p];
         chead[p] = s;
@@ -703,67 +728,43 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
           }
         continue;
       }
-      // bucket the stored lower entries of matrix k by permuted column, sort each bucket by permuted
-      // row and merge it against the (sorted) pattern column: cache-friendly, O(nnz log colsize).
-      std::vector<int64_t> bptr(n + 1, 0);
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
-      for (int32_t i = 0; i < n; ++i)
-        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
-          int32_t j = indices[k][e];
-          if (j > i || j < 0) continue;
-          __atomic_fetch_add(&bptr[std::min(iperm[i], iperm[j]) + 1], 1, __ATOMIC_RELAXED);
-        }
-      for (int32_t c = 0; c < n; ++c) bptr[c + 1] += bptr[c];
-      const int64_t cntk = bptr[n];
-      std::vector<int32_t> brow(cntk);
-      std::vector<int64_t> bsrc(cntk);
-      {
-        // (relaxed atomics on all cores; every bucket is sorted by (row, source) below, so the maps are deterministic)
-        std::vector<int64_t> fill(bptr.begin(), bptr.end() - 1);
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(BUCKET_THREADS)
-        for (int32_t i = 0; i < n; ++i)
-          for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
-            int32_t j = indices[k][e];
-            if (j > i || j < 0) continue;
-            int32_t a = iperm[i], b = iperm[j];
-            int64_t f = __atomic_fetch_add(&fill[std::min(a, b)], 1, __ATOMIC_RELAXED);
-            brow[f] = std::max(a, b);
-            bsrc[f] = e;
-          }
+      // every stored lower entry (i, j) looks its pattern slot up: column min(new i, new j), row max, found by bisection
+      // in the sorted column -- independent per entry, all cores, no scatter.  (A duplicate of an entry inside one
+      // matrix maps to the same slot; the value upload keeps one of them.)
+      std::vector<int64_t> lptr(n + 1, 0);
+#pragma omp parallel for schedule(static)
+      for (int32_t i = 0; i < n; ++i) {
+        int64_t c = 0;
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) c += indices[k][e] >= 0 && indices[k][e] <= i;
+        lptr[i + 1] = c;
       }
-      S->val_slot[k].resize(cntk);
-      S->val_src[k].resize(cntk);
-      lap("  bucket entries by column");
-#pragma omp parallel
-      {
-        std::vector<std::pair<int32_t, int64_t>> tmp;
-#pragma omp for schedule(dynamic, 256)
-        for (int32_t c = 0; c < n; ++c) {
-          int64_t b0 = bptr[c], b1 = bptr[c + 1];
-          tmp.resize(b1 - b0);
-          for (int64_t t = b0; t < b1; ++t) tmp[t - b0] = {brow[t], bsrc[t]};
-          std::sort(tmp.begin(), tmp.end());
-          const int32_t* lo = cidx.data() + cptr[c];
-          const int32_t* hi = cidx.data() + cptr[c + 1];
-          const int32_t* it = lo;
-          for (int64_t t = b0; t < b1; ++t) {
-            int32_t row = tmp[t - b0].first;
-            int64_t sl;
-            if (row == c) {
-              sl = slot_ptr[c];
-            } else {
-              while (it != hi && *it < row) ++it;
-              sl = slot_ptr[c] + 1 + (it - lo);
-            }
-            S->val_slot[k][t] = sl;
-            S->val_src[k][t] = tmp[t - b0].second;
+      for (int32_t i = 0; i < n; ++i) lptr[i + 1] += lptr[i];
+      S->val_slot[k].resize(lptr[n]);
+      S->val_src[k].resize(lptr[n]);
+#pragma omp parallel for schedule(dynamic, 256)
+      for (int32_t i = 0; i < n; ++i) {
+        int64_t t = lptr[i];
+        const int32_t a = iperm[i];
+        for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+          const int32_t j = indices[k][e];
+          if (j < 0 || j > i) continue;
+          const int32_t bq = iperm[j];
+          const int32_t c = std::min(a, bq), r = std::max(a, bq);
+          int64_t sl = slot_ptr[c];
+          if (r != c) {
+            const int32_t* lo = cidx.data() + cptr[c];
+            const int32_t* hi = cidx.data() + cptr[c + 1];
+            sl += 1 + (std::lower_bound(lo, hi, r) - lo);
           }
+          S->val_slot[k][t] = sl;
+          S->val_src[k][t] = e;
+          ++t;
         }
       }
     }
     S->nnz_pattern = slot_ptr[n];
   }
-  lap("  sort / merge buckets");
+  lap("  entries -> pattern slots");
   // ---------------------------------------------------------------- 10. left-looking update schedule
   {
     S->upd_ptr.assign(ns + 1, 0);

@@ -156,3 +156,40 @@ def test_lower_only_and_full_inputs_give_the_same_analysis():
         for key in ("perm", "colcount", "sn_start", "sn_rowptr", "sn_rows", "sn_parent", "sn_level"):
             assert np.array_equal(full.get(key), other.get(key)), key
         assert full.info().nnzL == other.info().nnzL and full.info().nnz_pattern == other.info().nnz_pattern
+
+
+@pytest.mark.parametrize("half", ["full", "lower"])
+def test_assembly_maps_place_every_value_in_its_panel_cell(half):
+    """h[val_slot] = data[val_src]; L[asm_dst[slot]] += sigma2_k * h[slot] must reproduce the lower triangle of
+    P (sum_k sigma2_k A_k) P^T in the panels (rows of a panel = sn_rows of its front), zeros elsewhere."""
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(2500, 0.01, 4)
+    n = A.shape[0]
+    mats = [A.tocsr(), sp.identity(n, format="csr")]
+    given = [sp.tril(m, format="csr") for m in mats] if half == "lower" else mats
+    sym = Symbolic(given, upload=False)
+    s2 = [0.37, 0.81]
+    info = sym.info()
+    L = np.zeros(info.nnzL_stored)
+    asm = sym.get("asm_dst")
+    h_all = np.zeros(info.nnz_pattern)
+    for k, m in enumerate(given):
+        slot, src = sym.get("val_slot:%d" % k), sym.get("val_src:%d" % k)
+        if slot.size == n and np.array_equal(np.sort(slot), np.arange(n)):  # diagonal-only matrix: one value per new row
+            L[sym.get("diag_dst")[slot]] += s2[k] * m.data[src]
+            continue
+        assert np.unique(slot).size == slot.size
+        h = np.zeros(info.nnz_pattern)
+        h[slot] = m.data[src]
+        h_all += s2[k] * h
+    L += np.bincount(asm, weights=h_all, minlength=L.size)
+    perm = sym.P()
+    V = (s2[0] * mats[0] + s2[1] * mats[1]).tocsr()[perm][:, perm].toarray()
+    st, rp, rows, loff = sym.get("sn_start"), sym.get("sn_rowptr"), sym.get("sn_rows"), sym.get("sn_loff")
+    for s in range(info.nsuper):
+        r = rows[rp[s]:rp[s + 1]]
+        w = st[s + 1] - st[s]
+        panel = L[loff[s]:loff[s] + r.size * w].reshape(w, r.size).T  # column-major panel
+        want = V[np.ix_(r, np.arange(st[s], st[s + 1]))]
+        assert np.array_equal(np.tril(panel[:w]), np.tril(want[:w])) and np.array_equal(panel[w:], want[w:])
+        assert not np.triu(panel[:w], 1).any()                        # nothing lands above the diagonal
