@@ -6,6 +6,7 @@
 
 #include "../../include/scilmm_hip.h"
 #include "handles.h"
+#include "host_threads.h"
 
 using scilmm::Symbolic;
 
@@ -13,6 +14,7 @@ extern "C" {
 
 int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const scilmm_options* opts, int32_t ngpus, scilmm_symbolic** out) {
+  scilmm::use_host_threads();
   (void)ngpus;
   if (!out || n < 0 || K <= 0 || !indptr || !indices) return SCILMM_ERR_ARG;
   scilmm::SymbolicOptions o;
@@ -69,6 +71,7 @@ int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
   }
 
 int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, int64_t* count) {
+  scilmm::use_host_threads();
   if (!h || !h->S || !what || !count) return SCILMM_ERR_ARG;
   if (!h->S->combos_built && !std::strncmp(what, "combo_", 6)) scilmm::build_tile_combos(h->S, nullptr);
   const Symbolic& S = *h->S;
@@ -126,6 +129,7 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
 }
 
 int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32_t method, int32_t* perm_out) {
+  scilmm::use_host_threads();
   if (n < 0 || !indptr || !indices || !perm_out) return SCILMM_ERR_ARG;
   // symmetrised adjacency without the diagonal
   std::vector<int64_t> gptr((size_t)n + 1, 0);
@@ -163,6 +167,7 @@ int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32
 
 int scilmm_fill_count(int32_t n, const int64_t* indptr, const int32_t* indices, const int32_t* perm, int64_t* nnzL,
                       double* flops, int32_t* max_colcount) {
+  scilmm::use_host_threads();
   if (n < 0 || !indptr || !indices) return SCILMM_ERR_ARG;
   scilmm::fill_count(n, indptr, indices, perm, nnzL, flops, max_colcount, nullptr);
   return SCILMM_OK;

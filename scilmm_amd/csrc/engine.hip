@@ -20,6 +20,7 @@
 #include "kernels.hip.h"
 #include "cellplan.hip.h"
 #include "handles.h"
+#include "host_threads.h"
 
 using namespace scilmm;
 
@@ -859,7 +860,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     };
     {
       const unsigned nth = (unsigned)std::max<int64_t>(
-          1, std::min<int64_t>(std::min(nc > 50000000 ? 48u : 16u, std::max(1u, std::thread::hardware_concurrency())), ntiles0));
+          1, std::min<int64_t>((nc > 50000000 ? 3 : 1) * scilmm::host_threads(), ntiles0));  // static shares: finer = better balanced
       std::vector<int64_t> cut(nth + 1, ntiles0);
       cut[0] = 0;
       for (unsigned k = 1; k < nth; ++k) {
@@ -954,7 +955,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         for (const Cell& c : cells) sorted[fill[(size_t)c.late * NL + c.level]++] = c;
         cells.swap(sorted);
       }
-      const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      const unsigned nth = (unsigned)std::max(1, std::min(16, scilmm::host_threads()));
       auto parallel_buckets = [&](const std::function<void(size_t)>& fn) {
         std::atomic<size_t> next{0};
         auto worker = [&]() {
@@ -2314,7 +2315,7 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) 
     const auto& src = S.val_src[k];
     // every pattern slot is written by exactly one entry: the permutation is split over a few host threads
     const size_t cnt = slot.size();
-    const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), cnt / (1 << 20) + 1));
+    const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)std::min(16, scilmm::host_threads()), cnt / (1 << 20) + 1));
     auto part = [&](unsigned q) {
       const size_t a = cnt * q / nth, b = cnt * (q + 1) / nth;
       for (size_t t = a; t < b; ++t) h[slot[t]] = data_k[src[t]];

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "../../include/scilmm_hip.h"
+#include "host_threads.h"
 
 namespace {
 
@@ -207,6 +208,7 @@ struct scilmm_ibd {
 extern "C" {
 
 int scilmm_ibd_build(int32_t n, const int32_t* parents, int32_t count_only, scilmm_ibd** out, int64_t* nnz) {
+  scilmm::use_host_threads();
   if (n < 0 || !parents || !out || !nnz) return SCILMM_ERR_ARG;
   scilmm_ibd* h = new scilmm_ibd();
   h->B.n = n;

@@ -23,6 +23,7 @@
 #endif
 
 #include "../../include/scilmm_hip.h"
+#include "host_threads.h"
 
 struct scilmm_mm {
   int32_t nrows = 0, ncols = 0;
@@ -76,6 +77,7 @@ inline const char* parse_line(const char* p, const char* e, bool pattern, Entry*
 extern "C" {
 
 int scilmm_mm_read(const char* path, scilmm_mm** out, int32_t* nrows, int32_t* ncols, int64_t* nnz) {
+  scilmm::use_host_threads();
   if (!path || !out) return SCILMM_ERR_ARG;
   scilmm_mm* M = new scilmm_mm();
   *out = M;

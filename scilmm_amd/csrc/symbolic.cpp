@@ -6,9 +6,11 @@
 // All algorithms are written from their published descriptions (Liu 1990 elimination tree with
 // path compression; Gilbert, Ng & Peyton 1994 skeleton column counts; Ashcraft & Grimes 1989 relaxed
 // supernode amalgamation); no third-party source was available in this container.
+#include "host_threads.h"
 #include "symbolic.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cstring>
 #include <numeric>
@@ -22,7 +24,7 @@ namespace {
 
 // team size of the bucket passes that count / fill with relaxed atomics: beyond a socket's worth of cores the cache-line
 // traffic of the shared counters costs more than the extra threads bring (measured on the 256-core GPU host)
-constexpr int BUCKET_THREADS = 16;
+#define BUCKET_THREADS std::min(16, host_threads())
 
 // CSC-lower (strict or with diagonal) <-> CSR-lower transpose of a pattern.
 void transpose_pattern(int32_t n, const std::vector<int64_t>& ptr, const std::vector<int32_t>& idx,
@@ -186,6 +188,7 @@ void fill_count(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, const int
 
 Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const SymbolicOptions& opts) {
+  use_host_threads();
   Symbolic* S = new Symbolic();
   S->n = n;
   S->K = K;
@@ -385,29 +388,26 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   std::vector<int32_t> nlarger(n);
   {
     std::vector<int32_t> anc(n, -1);
-    constexpr int32_t BLK = 16384;
-    std::vector<int32_t> buf, bcnt(BLK);
-    std::vector<int64_t> boff(BLK + 1);
-    for (int32_t i0 = 0; i0 < n; i0 += BLK) {
-      const int32_t i1 = std::min(n, i0 + BLK);
-      boff[0] = 0;
-      for (int32_t i = i0; i < i1; ++i) boff[i - i0 + 1] = boff[i - i0] + (gptr[perm[i] + 1] - gptr[perm[i]]);
-      if ((int64_t)buf.size() < boff[i1 - i0]) buf.resize(boff[i1 - i0]);
-#pragma omp parallel for schedule(dynamic, 64)
-      for (int32_t i = i0; i < i1; ++i) {
-        const int32_t v = perm[i];
-        int32_t* o = buf.data() + boff[i - i0];
-        int32_t m = 0;
-        for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
-          const int32_t k = iperm[gidx[e]];
-          if (k < i) o[m++] = k;
-        }
-        bcnt[i - i0] = m;
-        nlarger[v] = (int32_t)(gptr[v + 1] - gptr[v]) - m;
+    constexpr int32_t BLK = 32768;
+    const int32_t nblk = (n + BLK - 1) / BLK;
+    std::vector<int32_t> buf[2], bcnt[2];
+    std::vector<int64_t> boff[2];
+    for (int h = 0; h < 2; ++h) { bcnt[h].resize(BLK); boff[h].resize(BLK + 1); }
+    auto filter_row = [&](int h, int32_t i0, int32_t i) {
+      const int32_t v = perm[i];
+      int32_t* o = buf[h].data() + boff[h][i - i0];
+      int32_t m = 0;
+      for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
+        const int32_t k = iperm[gidx[e]];
+        if (k < i) o[m++] = k;
       }
+      bcnt[h][i - i0] = m;
+      nlarger[v] = (int32_t)(gptr[v + 1] - gptr[v]) - m;
+    };
+    auto consume = [&](int h, int32_t i0, int32_t i1) {
       for (int32_t i = i0; i < i1; ++i) {
-        const int32_t* o = buf.data() + boff[i - i0];
-        for (int32_t t = 0; t < bcnt[i - i0]; ++t) {
+        const int32_t* o = buf[h].data() + boff[h][i - i0];
+        for (int32_t t = 0; t < bcnt[h][i - i0]; ++t) {
           int32_t k = o[t];
           while (k != -1 && k < i) {
             const int32_t nx = anc[k];
@@ -417,6 +417,37 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
           }
         }
       }
+    };
+    // block b is consumed by one thread while the others filter block b + 1
+    for (int32_t b = -1; b < nblk; ++b) {
+      const int hn = (b + 1) & 1;
+      const int32_t n0 = (b + 1) * BLK, n1 = std::min<int64_t>(n, (int64_t)(b + 2) * BLK);
+      if (b + 1 < nblk) {
+        boff[hn][0] = 0;
+        for (int32_t i = n0; i < n1; ++i) boff[hn][i - n0 + 1] = boff[hn][i - n0] + (gptr[perm[i] + 1] - gptr[perm[i]]);
+        if ((int64_t)buf[hn].size() < boff[hn][n1 - n0]) buf[hn].resize(boff[hn][n1 - n0]);
+      }
+      std::atomic<int32_t> next{n0};
+      bool consumed = false;
+#pragma omp parallel
+      {
+#ifdef _OPENMP
+        const bool consumer = omp_get_thread_num() == 0 && omp_get_num_threads() > 1;
+#else
+        const bool consumer = false;
+#endif
+        if (consumer) {
+          if (b >= 0) consume(b & 1, b * BLK, std::min<int64_t>(n, (int64_t)(b + 1) * BLK));
+          consumed = true;
+        } else if (b + 1 < nblk) {
+          for (;;) {
+            const int32_t i = next.fetch_add(64, std::memory_order_relaxed);
+            if (i >= n1) break;
+            for (int32_t q = i; q < std::min(n1, i + 64); ++q) filter_row(hn, n0, q);
+          }
+        }
+      }
+      if (!consumed && b >= 0) consume(b & 1, b * BLK, std::min<int64_t>(n, (int64_t)(b + 1) * BLK));  // team of one
     }
   }
   std::vector<int32_t> post;
@@ -728,6 +759,93 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
           }
         continue;
       }
+      // Fast path -- matrix k stores both halves, rows strictly ascending (canonical CSR).  Vertex v's pattern column
+      // c = new(v) is walked once: positions of its rows go to a thread-local table, and every entry (v, u) of row v
+      // with new(u) >= c finds its slot there -- the column is warm, nothing is searched.  The value is read from the
+      // stored LOWER entry: (v, u) itself if u <= v, else its mirror (u, v), whose index inside row u is the number of
+      // smaller columns in that row = the running count of mirrors seen while the rows are swept in ascending order
+      // (done per range of target rows, one range per thread, so the counts need no atomics).
+      bool fast = true;
+      {
+        uint64_t hlo = 0, hup = 0;
+        int64_t bad = 0;
+        auto mix = [](uint64_t x) {
+          x += 0x9e3779b97f4a7c15ull;
+          x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+          x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+          return x ^ (x >> 31);
+        };
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : hlo, hup, bad)
+        for (int32_t i = 0; i < n; ++i)
+          for (int64_t e = indptr[k][i]; e < indptr[k][i + 1]; ++e) {
+            const int32_t j = indices[k][e];
+            if (j < 0 || j >= n || (e > indptr[k][i] && indices[k][e - 1] >= j)) { ++bad; continue; }
+            if (j < i) hlo += mix(((uint64_t)(uint32_t)i << 32) | (uint32_t)j);
+            else if (j > i) hup += mix(((uint64_t)(uint32_t)j << 32) | (uint32_t)i);
+          }
+        fast = bad == 0 && hlo == hup;
+      }
+      if (fast) {
+        const int64_t* ip = indptr[k];
+        const int32_t* ix = indices[k];
+        const int64_t nzk = ip[n];
+        // mirror positions of the upper entries
+        std::vector<int32_t> mir(nzk);
+        {
+          const int R = std::max(1, host_threads());
+          std::vector<int64_t> lowcum(n + 1, 0);
+#pragma omp parallel for schedule(static)
+          for (int32_t i = 0; i < n; ++i) lowcum[i + 1] = std::lower_bound(ix + ip[i], ix + ip[i + 1], i) - (ix + ip[i]);
+          for (int32_t i = 0; i < n; ++i) lowcum[i + 1] += lowcum[i];
+          std::vector<int32_t> cut(R + 1, n);
+          cut[0] = 0;
+          for (int q = 1; q < R; ++q)
+            cut[q] = (int32_t)(std::lower_bound(lowcum.begin(), lowcum.end(), lowcum[n] * q / R) - lowcum.begin());
+          for (int q = 1; q <= R; ++q) cut[q] = std::max(cut[q], cut[q - 1]);
+#pragma omp parallel for schedule(dynamic, 1)
+          for (int q = 0; q < R; ++q) {
+            const int32_t i0 = cut[q], i1 = cut[q + 1];
+            if (i1 <= i0) continue;
+            std::vector<int32_t> cur(i1 - i0, 0);
+            for (int32_t j = 0; j < i1; ++j) {  // rows j >= i1 have no upper entry below i1
+              const int32_t* b = ix + ip[j];
+              const int32_t* e = ix + ip[j + 1];
+              const int32_t* lo = std::lower_bound(b, e, std::max(i0, j + 1));
+              for (const int32_t* t = lo; t < e && *t < i1; ++t) mir[t - ix] = cur[*t - i0]++;
+            }
+          }
+        }
+        std::vector<int64_t> optr(n + 1, 0);
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int32_t v = 0; v < n; ++v) {
+          const int32_t c = iperm[v];
+          int64_t m = 0;
+          for (int64_t e = ip[v]; e < ip[v + 1]; ++e) m += iperm[ix[e]] >= c;
+          optr[v + 1] = m;
+        }
+        for (int32_t v = 0; v < n; ++v) optr[v + 1] += optr[v];
+        S->val_slot[k].resize(optr[n]);
+        S->val_src[k].resize(optr[n]);
+#pragma omp parallel
+        {
+          std::vector<int32_t> pos(n, -1);
+#pragma omp for schedule(dynamic, 256)
+          for (int32_t v = 0; v < n; ++v) {
+            const int32_t c = iperm[v];
+            for (int64_t e = cptr[c]; e < cptr[c + 1]; ++e) pos[cidx[e]] = (int32_t)(e - cptr[c]);
+            int64_t t = optr[v];
+            for (int64_t e = ip[v]; e < ip[v + 1]; ++e) {
+              const int32_t u = ix[e], r = iperm[u];
+              if (r < c) continue;
+              S->val_slot[k][t] = r == c ? slot_ptr[c] : slot_ptr[c] + 1 + pos[r];
+              S->val_src[k][t] = u <= v ? e : ip[u] + mir[e];
+              ++t;
+            }
+          }
+        }
+        continue;
+      }
+      // General inputs (one half stored, unsorted rows, duplicates):
       // every stored lower entry (i, j) looks its pattern slot up: column min(new i, new j), row max, found by bisection
       // in the sorted column -- independent per entry, all cores, no scatter.  (A duplicate of an entry inside one
       // matrix maps to the same slot; the value upload keeps one of them.)
@@ -856,6 +974,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 // that land in it.  keep_front (optional, [nsuper]) restricts the enumeration to the targets a rank owns in a
 // multi-GPU run; the lists of the other tiles stay empty.
 void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense, const uint8_t* skip_desc) {
+  use_host_threads();
   const int32_t ns = S->nsuper;
   const int32_t TM = S->tile_rows;
   const int64_t nt = S->tile_base[ns];

@@ -193,3 +193,35 @@ def test_assembly_maps_place_every_value_in_its_panel_cell(half):
         want = V[np.ix_(r, np.arange(st[s], st[s + 1]))]
         assert np.array_equal(np.tril(panel[:w]), np.tril(want[:w])) and np.array_equal(panel[w:], want[w:])
         assert not np.triu(panel[:w], 1).any()                        # nothing lands above the diagonal
+
+
+def test_large_sparse_graph_blocks_of_the_analysis_agree_with_the_plain_path():
+    """n = 90 000 (several 32k-row blocks of the pipelined elimination-tree pass; 5-point grid, randomly labelled):
+    the fill equals the one of the independent etree + column-count routine, full / lower-only inputs give the same
+    value maps, and val_src always points at a stored LOWER entry."""
+    from scilmm_amd import _lib
+    rng = np.random.default_rng(0)
+    m = 300
+    n = m * m
+    idx = np.arange(n).reshape(m, m)
+    rows = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+    cols = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+    p0 = rng.permutation(n)
+    R = sp.coo_matrix((rng.random(rows.size), (p0[rows], p0[cols])), shape=(n, n)).tocsr()
+    A = (R + R.T + sp.identity(n) * 10).tocsr()
+    A.sort_indices()
+    I = sp.identity(n, format="csr")
+    sym = Symbolic([A, I], upload=False)
+    perm = sym.get("perm")
+    nz, _, _ = _lib.fill_count(A, perm)
+    assert sym.info().nnzL == nz
+    T = sp.tril(A, format="csr")
+    lower = Symbolic([T, I], upload=False)
+    assert np.array_equal(lower.get("perm"), perm) and lower.info().nnzL == nz
+    s1, r1 = sym.get("val_slot:0"), sym.get("val_src:0")
+    s2, r2 = lower.get("val_slot:0"), lower.get("val_src:0")
+    a, b = np.argsort(s1), np.argsort(s2)
+    assert np.array_equal(s1[a], s2[b]) and np.unique(s1).size == s1.size
+    assert np.array_equal(A.data[r1[a]], T.data[r2[b]])
+    rowof = np.repeat(np.arange(n), np.diff(A.indptr))
+    assert (A.indices[r1] <= rowof[r1]).all()
