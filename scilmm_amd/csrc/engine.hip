@@ -126,6 +126,8 @@ struct Dev {
   bool dense_on = false;
   int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
   int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
+  int dense_glds = 1;                   // staging of the 16x16x4 form: 1 = LDS-DMA (k_dense_g), 0 = through registers (k_dense)
+  double* d_zeros = nullptr;            // 2 KiB of zeros: source of the k-rows past a descendant's end (k_dense_g)
   DenseWork* d_dwork_e = nullptr;
   DenseWork* d_dwork_l = nullptr;
   std::vector<int64_t> dwork_e_ptr, dwork_l_ptr;  // [nlevels+1]
@@ -554,6 +556,12 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     D->dense_on = S.dense_first < S.nsuper && (edn ? edn[0] != '0' : tail_w >= 32768);
     const char* emf = tune_env("SCILMM_DENSE_MF");
     if (emf) D->dense_mf = atoi(emf) == 4 ? 4 : 16;
+    const char* egl = tune_env("SCILMM_DENSE_GLDS");
+    if (egl) D->dense_glds = egl[0] != '0';
+    if (D->dense_on && !D->d_zeros) {
+      HIPCHK(hipMalloc((void**)&D->d_zeros, 2048));
+      HIPCHK(hipMemset(D->d_zeros, 0, 2048));
+    }
   }
   {
     // k_outside takes over the update pairs (tail target, prelude descendant below the tail's first level) unless the
@@ -1318,9 +1326,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if ((st = upload(sym, D, dwork_l, &ddw)) != SCILMM_OK) return st;
       D->d_dwork_l = (DenseWork*)ddw;
       if (getenv("SCILMM_VERBOSE"))
-        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d)\n",
+        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d%s)\n",
                 S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,
-                (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels], D->dense_mf);
+                (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels], D->dense_mf,
+                D->dense_mf == 16 && D->dense_glds ? ", LDS-DMA staging" : "");
     }
     if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
     {
@@ -1535,6 +1544,7 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_g, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1699,6 +1709,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       hipLaunchKernelGGL((k_dense<4, false>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
     else if (D->dense_mf == 4)
       hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
+    else if (D->dense_glds)
+      hipLaunchKernelGGL(k_dense_g, dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half,
+                         (const double*)D->d_zeros);
     else
       hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
     launches++;

@@ -1122,6 +1122,113 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_dense_g: k_dense<16, true> with the staging done by LDS-DMA (global_load_lds_dwordx4, gfx950): a wave-instruction
+// moves 64 x 16 bytes from per-lane global addresses straight into 1 KiB of contiguous LDS -- exactly one k-row of
+// the B image (128 columns) or half a k-row of the A image (128 of the 256 rows), the padding between k-rows stays.
+// No staging registers, no ds_write pass, no selects: the copy of chunk c+1 into the other buffer is issued right
+// after the barrier that retired that buffer's readers and lands while the MFMAs of chunk c run; one vmcnt(0) +
+// barrier per chunk.  k-rows past the end of a descendant are sourced from a zero page (`zeros`, >= 1 KiB), rows /
+// columns past the item's edge from row / column 0 (their accumulators are never stored).
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gl_vptr;
+__global__ __launch_bounds__(512, 1) void k_dense_g(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, double* __restrict__ scratch,
+                                                    const double* __restrict__ zeros) {
+  static_assert(KC == 16 && NB == 128 && DTR == 256, "k_dense_g: 8 waves x (2 A k-rows x 2 halves + 2 B k-rows) per chunk");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Abuf = smem;                      // [2][KC][LDA2]
+  double* Bbuf = smem + 2 * KC * LDA2;      // [2][KC][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  // per-lane source offsets (doubles) inside a panel column: row pair of each A half, column pair of B
+  const int32_t a_off0 = R0 + (2 * lane < nrow ? 2 * lane : 0);
+  const int32_t a_off1 = R0 + (TM + 2 * lane < nrow ? TM + 2 * lane : 0);
+  const int32_t b_off = 2 * lane < wj ? 2 * lane : 0;
+  const double* zsrc = zeros + 2 * lane;
+  int32_t kd = wk.k0, kk0 = 0;
+  int kc_ld = 0;
+  auto issue_chunk = [&](int b) {
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    const int64_t md = S.n - c0d;
+    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
+    kc_ld = min(KC, wd - kk0);
+    double* As = Abuf + b * KC * LDA2;
+    double* Bs = Bbuf + b * KC * LDB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = 2 * wv + i;
+      const double* col = Pd + (int64_t)kr * md;
+      const bool in = kr < kc_ld;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(in ? col + a_off0 : zsrc), (lds_vptr)(As + kr * LDA2), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_vptr)(in ? col + a_off1 : zsrc), (lds_vptr)(As + kr * LDA2 + TM), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = wv + 8 * i;
+      const bool in = kr < kc_ld;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(in ? Pd + (int64_t)kr * md + b_off : zsrc), (lds_vptr)(Bs + kr * LDB), 16, 0, 0);
+    }
+    kk0 += KC;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+  };
+  d4 acc16[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  const int li = lane & 15, lk = lane >> 4;
+  if (wk.k0 >= wk.k1) return;
+  issue_chunk(0);
+  int kc_cur = kc_ld;
+  __syncthreads();  // (hipcc drains the outstanding LDS-DMA -- vmcnt(0) -- ahead of the barrier)
+  int buf = 0;
+  while (true) {
+    const bool more = kd < wk.k1;
+    if (more) issue_chunk(buf ^ 1);
+    const double* Ac = Abuf + buf * KC * LDA2;
+    const double* Bc = Bbuf + buf * KC * LDB;
+    const int kc4 = (kc_cur + 3) & ~3;
+#pragma unroll 2
+    for (int k4 = 0; k4 < kc4; k4 += 4) {
+      const double a0 = Ac[(k4 + lk) * LDA2 + 32 * wv + li], a1 = Ac[(k4 + lk) * LDA2 + 32 * wv + 16 + li];
+      double b[NJB];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
+        acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
+      }
+    }
+    if (!more) break;
+    kc_cur = kc_ld;
+    __syncthreads();
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 32 * wv + 16 * ib + li, jc = 16 * jb + lk + 4 * r;
+        const double v = acc16[jb][ib][r];
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+        }
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_dense32: the dense-tail update with the PRODUCTS on the fp32 matrix pipe and the SUMS in fp64 -- the
 // "fp64 factor with fp32 MFMA fronts" of BASELINE configs[4] (opt-in: scilmm_set_front_precision(sym, 32)).
 // Operands are rounded to fp32 when they are staged into LDS (the image is half as large), a 16-deep chunk is

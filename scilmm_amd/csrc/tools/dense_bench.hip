@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 #include "../kernels.hip.h"
 using namespace scilmm;
@@ -60,6 +61,10 @@ int main(int argc, char** argv) {
   const size_t sm = sizeof(double) * (size_t)(2 * KC * LDA2 + 2 * KC * LDB);
   CK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_dense_g, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  double* zeros;
+  CK(hipMalloc(&zeros, 2048));
+  CK(hipMemset(zeros, 0, 2048));
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -68,13 +73,14 @@ int main(int argc, char** argv) {
   printf("T=%d panels, target %d: %zu items (%d descendants each), %.3f TFLOP per launch, %.1f MB of slabs\n", T, j, work.size(), per,
          flops / 1e12, slot * TM * NB * 8 / 1e6);
   for (int fill : {0, 1})
-  for (int mf : {16, 4, 32}) {
+  for (int mf : {16, 160, 4, 32}) {
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, (size_t)sn_loff[T], fill);
     for (int rep = 0; rep < 3; ++rep) {
       unsigned long long z[2] = {0, 0};
       CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dense_clk), z, sizeof(z)));
       hipEventRecord(e0);
       if (mf == 16) hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
+      else if (mf == 160) hipLaunchKernelGGL(k_dense_g, dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else if (mf == 4) hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
       else hipLaunchKernelGGL(k_dense32, dim3((unsigned)work.size()), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), 0, S, 0, d_work, L, scratch);
       hipEventRecord(e1);
@@ -83,10 +89,26 @@ int main(int argc, char** argv) {
       hipEventElapsedTime(&ms, e0, e1);
       CK(hipGetLastError());
       CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_dense_clk), sizeof(z)));
-      if (rep && mf != 32) printf("k_dense<%d>, %s operands: %.3f ms -> %.2f TFLOP/s at %.2f GHz shader clock\n", mf, fill ? "random" : "zero", ms,
+      if (rep && mf == 160) printf("k_dense_g (LDS-DMA staging), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
+      else if (rep && mf != 32) printf("k_dense<%d>, %s operands: %.3f ms -> %.2f TFLOP/s at %.2f GHz shader clock\n", mf, fill ? "random" : "zero", ms,
                       flops / ms / 1e9, 0.1 * (double)z[1] / (double)z[0]);
       if (rep && mf == 32) printf("k_dense32 (fp32 products, fp64 sums), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
     }
+  }
+  {
+    // same slabs from both staging forms (random operands; the arithmetic order is identical, so the bits are too)
+    const size_t ns = (size_t)slot * TM * NB;
+    std::vector<double> r0(ns), r1(ns);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, (size_t)sn_loff[T], 1);
+    CK(hipMemset(scratch, 0, sizeof(double) * ns));
+    hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
+    CK(hipMemcpy(r0.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    CK(hipMemset(scratch, 0, sizeof(double) * ns));
+    hipLaunchKernelGGL(k_dense_g, dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+    CK(hipMemcpy(r1.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    double mx = 0, ref = 0;
+    for (size_t i = 0; i < ns; ++i) { mx = std::max(mx, std::fabs(r0[i] - r1[i])); ref = std::max(ref, std::fabs(r0[i])); }
+    printf("k_dense_g vs k_dense<16>: max |difference| of the slabs %.3g (largest entry %.3g)\n", mx, ref);
   }
   return 0;
 }
