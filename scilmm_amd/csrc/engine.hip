@@ -1942,6 +1942,16 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       // ---- every prelude front below the tail's first level is final: its contribution to the tail, in ITS
       //      coordinates, with atomic subtraction (k_outside); nothing else touches a tail panel meanwhile
       HIPCHK(hipStreamWaitEvent(D->outside_st, D->lev_ev[2 * l], 0));
+#ifdef SCILMM_DIAG
+      if (D->ablate == 6 || D->ablate == 7) {  // timing ablations: no scatter / plain stores (WRONG numbers)
+        if (D->ablate == 6)
+          hipLaunchKernelGGL((k_outside<true, 1>), dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
+                             (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+        else
+          hipLaunchKernelGGL((k_outside<true, 2>), dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
+                             (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+      } else
+#endif
       if (D->use_mfma)
         hipLaunchKernelGGL(k_outside<true>, dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
                            (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
@@ -2064,7 +2074,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
     if (const char* dump = getenv("SCILMM_LEVEL_DUMP")) {
       // diagnostic: one line per level (durations in ms; cost = combos + K-chunks of the level's dense work)
       if (FILE* fp = fopen(dump, "w")) {
-        fprintf(fp, "level,fronts,tiles,items_early,items_late,cost_early,cost_late,early_ms,late_ms,mid_ms,potrf_ms,trsm_ms\n");
+        fprintf(fp, "level,fronts,tiles,items_early,items_late,cost_early,cost_late,early_ms,late_ms,mid_ms,potrf_ms,trsm_ms,t_potrf_ms,t_early0_ms,t_early1_ms,dense_early_ms,dense_late_ms\n");
         for (int32_t l = 0; l < S.nlevels; ++l) {
           float xe = 0, xl = 0, xm = 0, xp = 0, xt = 0;
           if (D->work_ptr[l + 1] > D->work_ptr[l]) HIPCHK(hipEventElapsedTime(&xl, D->pev[PE * l + 0], D->pev[PE * l + 1]));
@@ -2072,10 +2082,19 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
           HIPCHK(hipEventElapsedTime(&xm, D->pev[PE * l + 1], D->pev[PE * l + 2]));
           HIPCHK(hipEventElapsedTime(&xp, D->pev[PE * l + 2], D->pev[PE * l + 3]));
           HIPCHK(hipEventElapsedTime(&xt, D->pev[PE * l + 3], D->pev[PE * l + 4]));
-          fprintf(fp, "%d,%d,%lld,%lld,%lld,%lld,%lld,%.4f,%.4f,%.4f,%.4f,%.4f\n", l, S.level_ptr[l + 1] - S.level_ptr[l],
+          // absolute times since the start of the factorization: this level's potrf, its early dense launch (begin, end)
+          float tp = 0, te0 = 0, te1 = 0, de = 0, dl = 0;
+          HIPCHK(hipEventElapsedTime(&tp, D->ev[1], D->pev[PE * l + 2]));
+          if (D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l]) {
+            HIPCHK(hipEventElapsedTime(&te0, D->ev[1], D->pev[PE * l + 8]));
+            HIPCHK(hipEventElapsedTime(&te1, D->ev[1], D->pev[PE * l + 9]));
+            de = te1 - te0;
+          }
+          if (D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]) HIPCHK(hipEventElapsedTime(&dl, D->pev[PE * l + 10], D->pev[PE * l + 11]));
+          fprintf(fp, "%d,%d,%lld,%lld,%lld,%lld,%lld,%.4f,%.4f,%.4f,%.4f,%.4f,%.3f,%.3f,%.3f,%.4f,%.4f\n", l, S.level_ptr[l + 1] - S.level_ptr[l],
                   (long long)(S.level_tile_ptr[l + 1] - S.level_tile_ptr[l]), (long long)(D->early_ptr[l + 1] - D->early_ptr[l]),
                   (long long)(D->work_ptr[l + 1] - D->work_ptr[l]), (long long)D->lev_cost_e[l], (long long)D->lev_cost_l[l], xe, xl,
-                  xm, xp, xt);
+                  xm, xp, xt, tp, te0, te1, de, dl);
         }
         fclose(fp);
       }

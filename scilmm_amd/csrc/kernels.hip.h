@@ -1372,7 +1372,8 @@ struct OutsideWork {
   int32_t bi, bj;   // 128-row blocks of those rows: target rows / target columns
 };
 
-template <bool MFMA>
+// SCATTER: 0 = atomic subtraction (the product), 1 = nothing, 2 = plain stores (timing ablations of diagnostic builds)
+template <bool MFMA, int SCATTER = 0>
 __global__ __launch_bounds__(256) void k_outside(DevSym S, int32_t dense_first, const OutsideWork* __restrict__ work,
                                                  const int32_t* __restrict__ tail_front,  // tail column (label - c0_tail) -> front
                                                  const uint8_t* __restrict__ keep_front,  // multi-GPU: fronts this rank computes
@@ -1438,7 +1439,13 @@ __global__ __launch_bounds__(256) void k_outside(DevSym S, int32_t dense_first, 
       for (int ib = 0; ib < 2; ++ib) {
         const int iloc = 32 * wv + 16 * ib + li;
         const int32_t ci = lab_i[iloc];
-        if (ci >= cj) unsafeAtomicAdd(col + ci, -acc[jb][ib][r]);  // lower triangle only (ci = -1 for padding rows)
+        if (SCATTER == 0) {
+          if (ci >= cj) unsafeAtomicAdd(col + ci, -acc[jb][ib][r]);  // lower triangle only (ci = -1 for padding rows)
+        } else if (SCATTER == 1) {
+          if (ci >= cj && acc[jb][ib][r] == 123.456) col[ci] = 0.0;
+        } else {
+          if (ci >= cj) col[ci] = -acc[jb][ib][r];
+        }
       }
     }
 }

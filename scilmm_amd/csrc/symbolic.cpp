@@ -14,6 +14,7 @@
 #include <cassert>
 #include <cstring>
 #include <numeric>
+#include <queue>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -485,18 +486,11 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       }
       std::sort(cidx.begin() + cptr[c], cidx.begin() + cptr[c + 1]);
     }
-    std::vector<int32_t>().swap(gidx);
   }
   lap("permuted pattern");
-  S->perm = perm;
-  S->iperm = iperm;
-  S->parent = parent;
-
-  lap("etree+postorder+relabel");
   // ---------------------------------------------------------------- 5. column counts
   std::vector<int32_t> cc;
   column_counts(n, parent, post, cptr, cidx, cc);
-  S->colcount = cc;
   S->nnzL = 0;
   S->flops = 0;
   for (int32_t j = 0; j < n; ++j) {
@@ -623,17 +617,24 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       tmp.clear();
     }
   }
-  // ---------------------------------------------------------------- 7b. dense tail
-  // The trailing clique of a pedigree factor (16.6k columns at the 100k config, 170k at 1M; > 75 % / > 99 % of the
-  // flops) is a chain of fronts whose row lists are "almost every later column".  Padding those lists to EVERY later
-  // column (explicit zeros, like relaxed amalgamation) turns the tail into one dense lower-triangular matrix cut
-  // into block columns: updates inside it need no index lists, no descriptors and no gather.  The tail is grown from
-  // the last front downwards along the chain (parent = next front) while the padded flop count stays within
-  // dense_relax of the true one.
+  // ---------------------------------------------------------------- 7a. dense tail: which fronts
+  // The top of a pedigree factor (16.6k columns at the 100k config, 170k at 1M; > 75 % / > 99 % of the flops) consists
+  // of fronts whose row lists are "almost every later column".  Padding those lists to EVERY later column (explicit
+  // zeros, like relaxed amalgamation) turns that part into one dense lower-triangular matrix cut into block columns:
+  // updates inside it need no index lists, no descriptors and no gather.
+  // The tail T is an ancestor-closed set of fronts, grown from the roots of the supernodal tree downwards: among the
+  // fronts whose parent is already in T the one with the longest true row list is taken next, as long as its own list
+  // fills at least half of its padded one and the padded flop count of the whole tail stays within dense_relax of the
+  // true one.  T need not be a chain of the tree: at the 1M config two chains of near-dense fronts (45 x 128 columns
+  // with 126k rows each beside the main one) merge 46 levels above the tail's start; as a side branch their updates
+  // of the tail went through the gather path at 11 TFLOP/s (a fifth of the factorization time), inside T they are
+  // k_dense work.  The fronts of T are moved to the end of the elimination order (children still precede parents, so
+  // the fill is unchanged) in the reverse order in which they were taken.
+  // A user-supplied permutation is never changed: then T is the trailing chain (parent = next front) only.
   S->dense_first = ns;
-  if (opts.dense_relax > 0.0) {
+  int32_t best = ns;
+  if (opts.dense_relax > 0.0 && opts.ordering == 2) {
     double fl_dense = 0.0, fl_true = 0.0;
-    int32_t best = ns;
     for (int32_t q = ns - 1; q >= 0; --q) {
       if (q < ns - 1 && S->sn_parent[q] != q + 1) break;
       const double w = out[q].end - out[q].start, mt = (double)(S->sn_rowptr[q + 1] - S->sn_rowptr[q]), md = (double)(n - out[q].start);
@@ -642,6 +643,118 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       if (fl_dense <= opts.dense_relax * fl_true) best = q;
       else if (fl_dense > 1.5 * fl_true) break;
     }
+  } else if (opts.dense_relax > 0.0) {
+    std::vector<int32_t> chead(ns, -1), cnext(ns, -1);
+    for (int32_t q = 0; q < ns; ++q)
+      if (S->sn_parent[q] != -1) { cnext[q] = chead[S->sn_parent[q]]; chead[S->sn_parent[q]] = q; }
+    std::priority_queue<std::pair<int64_t, int32_t>> heap;  // (true rows, front): longest list first, then the later front
+    for (int32_t q = 0; q < ns; ++q)
+      if (S->sn_parent[q] == -1) heap.push({S->sn_rowptr[q + 1] - S->sn_rowptr[q], q});
+    std::vector<int32_t> taken;
+    double fl_dense = 0.0, fl_true = 0.0;
+    int64_t cols_after = 0, best_cols = 0;
+    double best_ratio = 0.0;
+    size_t nbest = 0;
+    while (!heap.empty()) {
+      const int32_t q = heap.top().second;
+      heap.pop();
+      const double w = out[q].end - out[q].start, mt = (double)(S->sn_rowptr[q + 1] - S->sn_rowptr[q]), md = (double)cols_after + w;
+      if (2.0 * mt < md) continue;  // its list only gets relatively shorter as T grows: never eligible again
+      fl_dense += w * md * md;
+      fl_true += w * mt * mt;
+      taken.push_back(q);
+      cols_after += (int64_t)w;
+      if (fl_dense <= opts.dense_relax * fl_true) { nbest = taken.size(); best_cols = cols_after; best_ratio = fl_dense / fl_true; }
+      else if (fl_dense > 1.5 * fl_true) break;
+      for (int32_t c = chead[q]; c != -1; c = cnext[c]) heap.push({S->sn_rowptr[c + 1] - S->sn_rowptr[c], c});
+    }
+    if (nbest >= 4) {
+      taken.resize(nbest);
+      std::reverse(taken.begin(), taken.end());
+      best = ns - (int32_t)nbest;
+      bool in_place = true;
+      for (size_t t = 0; t < nbest; ++t) in_place = in_place && taken[t] == best + (int32_t)t;
+      if (verbose)
+        fprintf(stderr, "[scilmm symbolic] dense tail: %zu fronts, %lld columns, padded / true flops %.3f%s\n", nbest,
+                (long long)best_cols, best_ratio, in_place ? "" : " (moved to the end of the order)");
+      if (!in_place) {
+        // new front order = the others as they are, then T; everything computed so far is relabelled
+        std::vector<uint8_t> inT(ns, 0);
+        for (int32_t q : taken) inT[q] = 1;
+        std::vector<int32_t> order;
+        order.reserve(ns);
+        for (int32_t q = 0; q < ns; ++q)
+          if (!inT[q]) order.push_back(q);
+        order.insert(order.end(), taken.begin(), taken.end());
+        std::vector<int32_t> newlab(n), newsn(ns);
+        std::vector<SN> out2(ns);
+        {
+          int32_t c = 0;
+          for (int32_t k = 0; k < ns; ++k) {
+            const int32_t q = order[k];
+            newsn[q] = k;
+            out2[k] = out[q];
+            out2[k].start = c;
+            for (int32_t j = out[q].start; j < out[q].end; ++j) newlab[j] = c++;
+            out2[k].end = c;
+          }
+        }
+        std::vector<int32_t> perm2(n), par2(n), cc2(n);
+        for (int32_t j = 0; j < n; ++j) {
+          perm2[newlab[j]] = perm[j];
+          par2[newlab[j]] = parent[j] == -1 ? -1 : newlab[parent[j]];
+          cc2[newlab[j]] = cc[j];
+        }
+        perm.swap(perm2);
+        parent.swap(par2);
+        cc.swap(cc2);
+        for (int32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
+        // row lists: relabel, sort, store in the new front order
+        std::vector<int64_t> rp2(ns + 1, 0);
+        for (int32_t k = 0; k < ns; ++k) rp2[k + 1] = rp2[k] + (S->sn_rowptr[order[k] + 1] - S->sn_rowptr[order[k]]);
+        std::vector<int32_t> rows2(rp2[ns]);
+        std::vector<int32_t> spar2(ns);
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int32_t k = 0; k < ns; ++k) {
+          const int32_t q = order[k];
+          const int64_t b = S->sn_rowptr[q], e = S->sn_rowptr[q + 1];
+          int32_t* o = rows2.data() + rp2[k];
+          for (int64_t t = b; t < e; ++t) o[t - b] = newlab[S->sn_rows[t]];
+          const int32_t wq = out[q].end - out[q].start;
+          std::sort(o + wq, o + (e - b));  // (own columns stay first and ascending)
+          spar2[k] = S->sn_parent[q] == -1 ? -1 : newsn[S->sn_parent[q]];
+        }
+        S->sn_rows.swap(rows2);
+        S->sn_rowptr.swap(rp2);
+        S->sn_parent.swap(spar2);
+        out.swap(out2);
+        for (int32_t k = 0; k < ns; ++k) {
+          S->sn_start[k] = out[k].start;
+          for (int32_t j = out[k].start; j < out[k].end; ++j) snode_of[j] = k;
+        }
+        // the permuted pattern under the new labels, again straight from G
+        for (int32_t c = 0; c < n; ++c) cptr[c + 1] = cptr[c] + nlarger[perm[c]];
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int32_t c = 0; c < n; ++c) {
+          const int32_t v = perm[c];
+          int64_t f = cptr[c];
+          for (int64_t e = gptr[v]; e < gptr[v + 1]; ++e) {
+            const int32_t r = iperm[gidx[e]];
+            if (r > c) cidx[f++] = r;
+          }
+          std::sort(cidx.begin() + cptr[c], cidx.begin() + cptr[c + 1]);
+        }
+      }
+    }
+  }
+  std::vector<int32_t>().swap(gidx);
+  S->perm = perm;
+  S->iperm = iperm;
+  S->parent = parent;
+  S->colcount = cc;
+  lap("dense tail selection");
+  // ---------------------------------------------------------------- 7b. dense tail: padding
+  if (opts.dense_relax > 0.0) {
     if (ns - best >= 4) {
       // algorithmic update flops of the fronts about to be padded, on their TRUE row lists (same formula as step 10)
       double true_tail = 0.0;
@@ -667,6 +780,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       for (int32_t q = best; q < ns; ++q) {
         for (int32_t r = out[q].start; r < n; ++r) S->sn_rows.push_back(r);
         S->sn_rowptr[q + 1] = (int64_t)S->sn_rows.size();
+        S->sn_parent[q] = q + 1 < ns ? q + 1 : -1;  // padded: the tail is a chain in index order
       }
     }
   }

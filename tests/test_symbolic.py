@@ -109,11 +109,14 @@ def test_empty_and_diagonal_inputs():
     assert Symbolic([one], upload=False).info().nnzL == 1
 
 
-def test_dense_tail_is_a_padded_chain():
-    """Step 7b of the analysis: the fronts from dense_first on have EVERY later column as a row, form a chain in
-    index order, cover the true structure, and cost at most dense_relax x the true flops of that tail."""
+@pytest.mark.parametrize("size,seed", [(10000, 5), (20000, 1)])
+def test_dense_tail_is_a_padded_chain(size, seed):
+    """Step 7 of the analysis: the fronts from dense_first on have EVERY later column as a row, form a chain in
+    index order, cover the true structure, and cost at most dense_relax x the true flops of that tail.  (In the second
+    case the tail is not a chain of the elimination tree: a side branch of near-dense fronts is moved to the end of the
+    order with it -- still a valid elimination order, so the reference analysis with that permutation has the same fill.)"""
     from tests.helpers import small_pedigree
-    A, _ = small_pedigree(10000, 0.01, 5)
+    A, _ = small_pedigree(size, 0.01, seed)
     n = A.shape[0]
     mats = [A, sp.identity(n, format="csr")]
     sym = Symbolic(mats, upload=False)
@@ -123,20 +126,32 @@ def test_dense_tail_is_a_padded_chain():
     assert int(ref.get("dense_first")[0]) == ref.info().nsuper
     assert 0 < df < ns and ns - df >= 4
     st, rp, rows, par = sym.get("sn_start"), sym.get("sn_rowptr"), sym.get("sn_rows"), sym.get("sn_parent")
-    assert np.array_equal(st, ref.get("sn_start"))
+    cc = ref.get("colcount")
+    assert np.array_equal(sym.get("colcount"), cc)  # same fill column by column
+    same_blocks = np.array_equal(st, ref.get("sn_start"))
+    assert same_blocks == (size == 10000)  # a moved tail keeps ITS blocks; a fresh analysis of that order cuts others
     rrp, rrows = ref.get("sn_rowptr"), ref.get("sn_rows")
     fl_dense = fl_true = 0.0
     for s in range(df, ns):
         assert np.array_equal(rows[rp[s]:rp[s + 1]], np.arange(st[s], n))
         assert par[s] == (s + 1 if s + 1 < ns else -1)
-        true_rows = rrows[rrp[s]:rrp[s + 1]]
-        assert np.isin(true_rows, rows[rp[s]:rp[s + 1]]).all()
         w = st[s + 1] - st[s]
+        if same_blocks:
+            true_rows = rrows[rrp[s]:rrp[s + 1]]
+            assert np.isin(true_rows, rows[rp[s]:rp[s + 1]]).all()
+            mt = float(true_rows.size)
+        else:
+            mt = float(cc[st[s]])  # the first column's count: a lower bound of the front's true row count
         fl_dense += w * float(n - st[s]) ** 2
-        fl_true += w * float(true_rows.size) ** 2
-    assert fl_dense <= 1.10 * fl_true
-    for s in range(df):  # everything below the tail is untouched
-        assert np.array_equal(rows[rp[s]:rp[s + 1]], rrows[rrp[s]:rrp[s + 1]])
+        fl_true += w * mt ** 2
+    assert fl_dense <= (1.10 if same_blocks else 1.15) * fl_true  # (the column-count bound is looser)
+    for s in range(df):  # everything below the tail: untouched / consistent with the column counts
+        if same_blocks:
+            assert np.array_equal(rows[rp[s]:rp[s + 1]], rrows[rrp[s]:rrp[s + 1]])
+        else:
+            r = rows[rp[s]:rp[s + 1]]
+            assert r.size >= cc[st[s]] and np.all(np.diff(r) > 0) and r[0] == st[s]
+            assert par[s] == -1 or par[s] > s
     assert sym.info().nnzL == ref.info().nnzL  # the algorithmic count does not include the padding
 
 
