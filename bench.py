@@ -56,17 +56,38 @@ def build_problem(name, seed):
     return mats[0], C, y
 
 
+def _effective_cpus():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(A, r, sample_name):
     """Supernodal BLAS-3 LL^T + solve on the host cores (oracle/supernodal_cpu.c).  Same ordering algorithm as
     the GPU run but its own analysis with 512-column blocks (what a CPU supernodal code wants)."""
     from oracle import oracle as O
     from scilmm_amd.factor import Symbolic
     n = A.shape[0]
+    # BLAS threads = the CPUs this process may really use (affinity mask AND cgroup quota: the GPU box shows 256 logical
+    # CPUs but grants 16 CPUs' worth of time; 64 BLAS threads under that quota ran 17-29 s, throttled at random)
+    cpus = _effective_cpus()
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threadpool_limits(limits=cpus, user_api="blas")
         threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
-        threads = len(os.sched_getaffinity(0))
+        threads = cpus
     csym = Symbolic([A, sp.identity(n, format="csr")], upload=False, max_width=512)
     cpu = O.SupernodalCPU(csym.arrays(), n)
     # values of V = 0.4 A + 0.6 I in pattern-slot order = CSC order of tril(V[P][:,P]) (diagonal first)
@@ -88,8 +109,8 @@ def cpu_baseline(A, r, sample_name):
     cinfo = csym.info()
     return {"value": cinfo.nnzL / (t_fact + t_solve), "unit": "nnz(L)/s", "cores": int(threads), "kind": "port",
             "sample": "the %s cohort (n=%d, nnz(L)=%.3g, %.3g flops), full factorization once: supernodal LL^T (%.2f s) + "
-                      "%d-column solve (%.2f s); oracle/supernodal_cpu.c with SciPy-bundled OpenBLAS (%d BLAS threads of %d "
-                      "visible cores), own AMD ordering, 512-column supernode blocks; CHOLMOD unavailable on this box"
+                      "%d-column solve (%.2f s); oracle/supernodal_cpu.c with SciPy-bundled OpenBLAS (%d BLAS threads = the CPU quota; %d "
+                      "logical CPUs visible), own AMD ordering, 512-column supernode blocks; CHOLMOD unavailable on this box"
                       % (sample_name, n, cinfo.nnzL, cinfo.flops, t_fact, r, t_solve, threads, len(os.sched_getaffinity(0))),
             "sample_workload": sample_name, "sample_nnzL": int(cinfo.nnzL), "sample_flops": cinfo.flops,
             "factor_s": t_fact, "solve_s": t_solve, "flops_per_s": cinfo.flops / t_fact, "logdet": cpu.logdet()}

@@ -46,8 +46,9 @@ typedef struct scilmm_options {
   int32_t max_width;    /* split supernodes wider than this (0 = library default) */
   double nd_oksep;      /* nested dissection: accept a separator only below this share of its subgraph (0 = default 0.1;
                            1.0 = always dissect, CHOLMOD's nd_oksep default) */
-  double dense_relax;   /* the trailing chain of fronts is padded to a dense block-column matrix while padded / true
-                           flops stay below this (0 = default 1.10; negative = never pad) */
+  double dense_relax;   /* the top of the elimination tree is padded to a dense block-column matrix while padded / true
+                           flops stay below this (0 = default: 1.10, and up to 1.25 once the tail is >= 32768 columns
+                           wide, where the dense kernel takes it over; negative = never pad) */
 } scilmm_options;
 
 typedef struct scilmm_info {

@@ -29,7 +29,7 @@ int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, c
     if (opts->amd_dense != 0) o.amd_dense = opts->amd_dense;
     if (opts->max_width != 0) o.max_width = opts->max_width < 0 ? 0 : opts->max_width;
     if (opts->nd_oksep > 0) o.nd_oksep = opts->nd_oksep;
-    if (opts->dense_relax != 0) o.dense_relax = opts->dense_relax < 0 ? 0.0 : opts->dense_relax;
+    if (opts->dense_relax != 0) o.dense_relax = o.dense_relax_wide = opts->dense_relax < 0 ? 0.0 : opts->dense_relax;  // explicit: one budget
   }
   if (perm_in && !opts) o.ordering = 2;
   scilmm_symbolic* h = new scilmm_symbolic();

@@ -1942,23 +1942,29 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       // ---- every prelude front below the tail's first level is final: its contribution to the tail, in ITS
       //      coordinates, with atomic subtraction (k_outside); nothing else touches a tail panel meanwhile
       HIPCHK(hipStreamWaitEvent(D->outside_st, D->lev_ev[2 * l], 0));
+      // (a launch carries at most 2^23 items: the dispatch packet counts WORK-ITEMS in 32 bits, 2^24 workgroups of 256
+      // threads would overflow it -- the 1M config with a short tail has 21M items)
+      for (int64_t o0 = 0; o0 < D->n_owork; o0 += (int64_t)1 << 23) {
+        const unsigned cnt = (unsigned)std::min<int64_t>((int64_t)1 << 23, D->n_owork - o0);
+        const OutsideWork* ow = (const OutsideWork*)D->d_owork + o0;
 #ifdef SCILMM_DIAG
-      if (D->ablate == 6 || D->ablate == 7) {  // timing ablations: no scatter / plain stores (WRONG numbers)
-        if (D->ablate == 6)
-          hipLaunchKernelGGL((k_outside<true, 1>), dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
-                             (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+        if (D->ablate == 6)  // timing ablations: no scatter / plain stores (WRONG numbers)
+          hipLaunchKernelGGL((k_outside<true, 1>), dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+        else if (D->ablate == 7)
+          hipLaunchKernelGGL((k_outside<true, 2>), dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
         else
-          hipLaunchKernelGGL((k_outside<true, 2>), dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
-                             (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
-      } else
 #endif
-      if (D->use_mfma)
-        hipLaunchKernelGGL(k_outside<true>, dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
-                           (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
-      else
-        hipLaunchKernelGGL(k_outside<false>, dim3((unsigned)D->n_owork), dim3(256), 0, D->outside_st, D->v, S.dense_first,
-                           (const OutsideWork*)D->d_owork, (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
-      launches++;
+        if (D->use_mfma)
+          hipLaunchKernelGGL(k_outside<true>, dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+        else
+          hipLaunchKernelGGL(k_outside<false>, dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+        HIPCHK(hipGetLastError());
+        launches++;
+      }
       HIPCHK(hipEventRecord(D->out_ev, D->outside_st));
       for (int32_t le = D->tail_level; le <= l + D->look_depth && le < S.nlevels; ++le) {
         if (le < 1) continue;

@@ -652,22 +652,28 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       if (S->sn_parent[q] == -1) heap.push({S->sn_rowptr[q + 1] - S->sn_rowptr[q], q});
     std::vector<int32_t> taken;
     double fl_dense = 0.0, fl_true = 0.0;
-    int64_t cols_after = 0, best_cols = 0;
-    double best_ratio = 0.0;
-    size_t nbest = 0;
+    int64_t cols_after = 0, best_cols = 0, wide_cols = 0;
+    double best_ratio = 0.0, wide_ratio = 0.0;
+    size_t nbest = 0, nwide = 0;
+    FILE* tail_dump = getenv("SCILMM_TAIL_DUMP") ? fopen(getenv("SCILMM_TAIL_DUMP"), "w") : nullptr;  // diagnostic: every candidate
+    if (tail_dump) fprintf(tail_dump, "taken,front,w,true_rows,padded_rows,fl_dense_before,fl_true_before\n");
     while (!heap.empty()) {
       const int32_t q = heap.top().second;
       heap.pop();
       const double w = out[q].end - out[q].start, mt = (double)(S->sn_rowptr[q + 1] - S->sn_rowptr[q]), md = (double)cols_after + w;
+      if (tail_dump) fprintf(tail_dump, "%d,%d,%.0f,%.0f,%.0f,%.6g,%.6g\n", (int)taken.size(), q, w, mt, md, fl_dense, fl_true);
       if (2.0 * mt < md) continue;  // its list only gets relatively shorter as T grows: never eligible again
       fl_dense += w * md * md;
       fl_true += w * mt * mt;
       taken.push_back(q);
       cols_after += (int64_t)w;
       if (fl_dense <= opts.dense_relax * fl_true) { nbest = taken.size(); best_cols = cols_after; best_ratio = fl_dense / fl_true; }
-      else if (fl_dense > 1.5 * fl_true) break;
+      if (fl_dense <= opts.dense_relax_wide * fl_true) { nwide = taken.size(); wide_cols = cols_after; wide_ratio = fl_dense / fl_true; }
+      if (fl_dense > 1.5 * fl_true) break;
       for (int32_t c = chead[q]; c != -1; c = cnext[c]) heap.push({S->sn_rowptr[c + 1] - S->sn_rowptr[c], c});
     }
+    if (tail_dump) fclose(tail_dump);
+    if (best_cols >= opts.dense_wide_cols && nwide > nbest) { nbest = nwide; best_cols = wide_cols; best_ratio = wide_ratio; }
     if (nbest >= 4) {
       taken.resize(nbest);
       std::reverse(taken.begin(), taken.end());

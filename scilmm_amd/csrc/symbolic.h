@@ -39,7 +39,12 @@ struct SymbolicOptions {
   double amd_dense = 10.0;     // rows with degree > amd_dense*sqrt(n) are ordered last
   int32_t max_width = SCILMM_NB; // split supernodes wider than this (the kernels' block width; 0 = unlimited)
   int32_t tile_rows = 128;     // rows per target tile of the update kernel
-  double dense_relax = 1.10;   // dense tail: padded / true flop ratio accepted when the trailing chain is made dense (0 = off)
+  double dense_relax = 1.10;   // dense tail: padded / true flop ratio accepted when the top of the tree is made dense (0 = off)
+  // A tail at least dense_wide_cols wide is updated by the descriptor-free dense kernel (engine: k_dense), 4-5 x faster
+  // per flop than the gather path its fronts would otherwise feed: there the tail may grow up to dense_relax_wide
+  // (every front it takes still fills >= half of its padded row list, i.e. costs <= 4 x its true flops).
+  double dense_relax_wide = 1.25;
+  int32_t dense_wide_cols = 32768;
 };
 
 // Everything the numeric phase needs.  "Front" s owns columns [sn_start[s], sn_start[s+1]) of the

@@ -204,6 +204,24 @@ def test_alternative_schedules_agree_with_oracle(monkeypatch, env):
     _check_factor([A, sp.identity(n, format="csr")], [0.35, 0.65], _engine([A, sp.identity(n, format="csr")]), rs=(5, 103))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"SCILMM_DENSE": "1"}, {"SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1"},
+                                 {"SCILMM_OUTSIDE": "1"}, {"SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1", "SCILMM_DENSE_GLDS": "0"}])
+def test_moved_dense_tail_matches_oracle(monkeypatch, env):
+    """A pedigree whose dense tail is NOT a chain of the elimination tree (a side branch of near-dense fronts joins it
+    and the tail is moved to the end of the order; symbolic.cpp step 7a): every schedule must match the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SCILMM_TUNING", "1")
+    A, _ = small_pedigree(20000, 0.01, 1)
+    n = A.shape[0]
+    sym = _engine([A, sp.identity(n, format="csr")])
+    st = sym.get("sn_start")
+    ref = _engine([A, sp.identity(n, format="csr")], upload=False, perm=sym.get("perm"), dense_relax=-1.0)
+    assert not np.array_equal(st, ref.get("sn_start"))  # the case really is a moved tail (see test_symbolic.py)
+    _check_factor([A, sp.identity(n, format="csr")], [0.35, 0.65], sym, rs=(5, 103))
+
+
 def test_async_refactorize_matches_blocking_call():
     """scilmm_refactorize_async + scilmm_factor_wait (and the implicit wait of every consumer) = scilmm_refactorize."""
     from scilmm_amd._lib import NotPositiveDefiniteError
