@@ -152,7 +152,7 @@ def ptr(a):
 
 _GET_DTYPES = {"sn_rowptr": np.int64, "sn_loff": np.int64, "asm_dst": np.int64, "diag_dst": np.int64,
                "upd_ptr": np.int64, "tile_base": np.int64, "combo_ptr": np.int64, "level_tile_ptr": np.int64,
-               "level_pair_ptr": np.int64, "child_ptr": np.int64, "pat_colptr": np.int64, "inv_off": np.int64}
+               "level_pair_ptr": np.int64, "child_ptr": np.int64, "tail_blk_ptr": np.int64, "pat_colptr": np.int64, "inv_off": np.int64}
 
 
 def symbolic_get(sym, name):

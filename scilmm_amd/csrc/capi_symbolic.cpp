@@ -123,6 +123,8 @@ int scilmm_symbolic_get(const scilmm_symbolic* h, const char* what, void* out, i
   GET("pat_colptr", pat_colptr)
   GET("pat_row", pat_row)
   GET("inv_off", inv_off)
+  GET("tail_blk_ptr", tail_blk_ptr)
+  GET("tail_blk", tail_blk)
   GET("child_ptr", child_ptr)
   GET("child_idx", child_idx)
   return SCILMM_ERR_ARG;

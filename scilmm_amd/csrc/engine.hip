@@ -1106,6 +1106,16 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       out.push_back(UpdWork{g, 0, a, ce});
       return (int64_t)(out.size() - first);
     };
+    // dense tail, block pattern: tail_src[j] = the tail fronts (relative index, ascending) whose TRUE row lists reach
+    // the columns of tail front j -- the others hold only padding there and are left out of j's dense items
+    std::vector<std::vector<int32_t>> tail_src;
+    if (D->dense_on && !S.tail_blk_ptr.empty()) {
+      const int32_t nT = S.nsuper - S.dense_first;
+      tail_src.resize((size_t)nT);
+      for (int32_t d = 0; d < nT; ++d)
+        for (int64_t e = S.tail_blk_ptr[d]; e < S.tail_blk_ptr[d + 1]; ++e) tail_src[(size_t)S.tail_blk[e]].push_back(d);
+    }
+    int64_t dense_pairs_all = 0, dense_pairs_kept = 0;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       int64_t total_e = 0, total_l = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
@@ -1116,6 +1126,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       // dense tail: the level's (single) front j = dense_first + jj receives every earlier tail front; the last
       // look_depth of them are "late", the others "early" -- implicit items, one per (pair of tiles, K segment)
       int32_t dj = -1, dcnt_e = 0, dcnt_l = 0;
+      std::vector<std::pair<int32_t, int32_t>> segs_e, segs_l;  // descendant ranges of the level's dense items
       const int64_t dunit = 1 + (NB + KC - 1) / KC;  // cost units of one tail descendant on one tile
       int32_t dfr = -1;  // the tail fronts lie on a chain: at most one of them per level
       if (D->dense_on)
@@ -1129,8 +1140,45 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           dcnt_l = lookahead ? std::min<int32_t>(depth, jj) : jj;
           dcnt_e = jj - dcnt_l;
           const int64_t ntl = S.tile_base[fr + 1] - S.tile_base[fr];
-          total_e += ntl * dunit * dcnt_e;
-          total_l += ntl * dunit * dcnt_l;
+          // K segments = contiguous ranges of ACTIVE descendants (the same for every tile of the front), about
+          // dense_items items per launch: every item writes two 128 KB slabs that k_reduce reads back, so few long
+          // items beat many short ones as long as the launch still fills the chip a few times over
+          const int64_t npairs = (ntl + 1) / 2;
+          const int64_t want = std::max<int64_t>(1, (dense_items + npairs / 2) / npairs);
+          auto build = [&](int32_t lo, int32_t hi, std::vector<std::pair<int32_t, int32_t>>& out) -> int64_t {
+            out.clear();
+            if (hi <= lo) return 0;
+            std::vector<std::pair<int32_t, int32_t>> runs;
+            if (tail_src.empty()) {
+              runs.push_back({lo, hi});
+            } else {
+              const std::vector<int32_t>& src = tail_src[(size_t)jj];
+              auto it = std::lower_bound(src.begin(), src.end(), lo);
+              for (; it != src.end() && *it < hi; ++it) {
+                if (!runs.empty() && runs.back().second == *it) runs.back().second = *it + 1;
+                else runs.push_back({*it, *it + 1});
+              }
+              if (runs.size() > 16) runs = {{runs.front().first, runs.back().second}};  // too fragmented: take the hull
+            }
+            int64_t total = 0;
+            for (auto& r : runs) total += r.second - r.first;
+            if (total == 0) return 0;
+            const int64_t nseg = std::min<int64_t>(std::min<int64_t>(64, total), want);
+            for (auto& r : runs) {
+              const int64_t len = r.second - r.first;
+              const int64_t ns_r = std::max<int64_t>(1, std::min<int64_t>(len, (nseg * len + total / 2) / total));
+              for (int64_t q = 0; q < ns_r; ++q) {
+                const int32_t a = r.first + (int32_t)(len * q / ns_r), b = r.first + (int32_t)(len * (q + 1) / ns_r);
+                if (b > a) out.push_back({a, b});
+              }
+            }
+            return total;
+          };
+          const int64_t act_e = build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
+          dense_pairs_all += jj;
+          dense_pairs_kept += act_e + act_l;
+          total_e += ntl * dunit * act_e;
+          total_l += ntl * dunit * act_l;
         }
       }
       const int64_t big = (int64_t)1 << 60;
@@ -1139,17 +1187,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       const int64_t per_e = allow_split ? std::min(cap_e, std::max<int64_t>(min_item, (total_e + target_items - 1) / target_items)) : big;
       const int64_t per_l = allow_split ? std::min(cap_l, std::max<int64_t>(min_item, (total_l + target_items - 1) / target_items)) : big;
       int64_t slots = 0;
-      // K segments of the dense-tail items (the same for every tile of the front) and, per tile, their first slab
-      // (their K range is cut so that a launch has about dense_items items: every item writes two 128 KB slabs that
-      // k_reduce reads back, so few long items beat many short ones as long as the launch still fills the chip a
-      // few times over -- measured at the 300k pedigree)
-      auto dense_nseg = [&](int32_t cnt, int64_t per_item) -> int64_t {
-        if (cnt <= 0) return 0;
-        (void)per_item;
-        const int64_t npairs = dj >= 0 ? (S.tile_base[dj + 1] - S.tile_base[dj] + 1) / 2 : 1;
-        return std::min<int64_t>(std::min<int64_t>(64, cnt), std::max<int64_t>(1, (dense_items + npairs / 2) / npairs));
-      };
-      const int64_t nde = dense_nseg(dcnt_e, per_e), ndl = dense_nseg(dcnt_l, per_l);
+      const int64_t nde = (int64_t)segs_e.size(), ndl = (int64_t)segs_l.size();
       std::vector<int32_t> dbase_e, dbase_l;  // per tile of front dj: first dense slab, -1 = subtract directly
       if (dj >= 0) {
         dbase_e.assign((size_t)(S.tile_base[dj + 1] - S.tile_base[dj]), -1);
@@ -1246,10 +1284,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         // K-segment major, tile-pair minor (same reason as above); a pair = two vertically adjacent tiles of the front
         const int32_t ntl = (int32_t)(S.tile_base[dj + 1] - S.tile_base[dj]);
         const int32_t jj = dj - S.dense_first;
-        auto emit = [&](std::vector<DenseWork>& out, int64_t nseg, int32_t kfirst, int32_t cnt, const std::vector<int32_t>& base) {
-          for (int64_t sg = 0; sg < nseg; ++sg) {
-            const int32_t k0 = kfirst + (int32_t)((int64_t)cnt * sg / nseg), k1 = kfirst + (int32_t)((int64_t)cnt * (sg + 1) / nseg);
-            if (k1 <= k0) continue;
+        auto emit = [&](std::vector<DenseWork>& out, const std::vector<std::pair<int32_t, int32_t>>& segs, const std::vector<int32_t>& base) {
+          for (size_t sg = 0; sg < segs.size(); ++sg) {
+            const int32_t k0 = segs[sg].first, k1 = segs[sg].second;
             for (int32_t q = 0; q < ntl; q += 2) {
               const int32_t nt2 = std::min<int32_t>(2, ntl - q);
               DenseWork wk{dj, q, nt2, k0, k1, base[(size_t)q] < 0 ? -1 : base[(size_t)q] + (int32_t)sg,
@@ -1258,8 +1295,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
             }
           }
         };
-        emit(dwork_e, nde, 0, dcnt_e, dbase_e);
-        emit(dwork_l, ndl, jj - dcnt_l, dcnt_l, dbase_l);
+        emit(dwork_e, segs_e, dbase_e);
+        emit(dwork_l, segs_l, dbase_l);
       }
       D->dwork_e_ptr[l + 1] = (int64_t)dwork_e.size();
       D->dwork_l_ptr[l + 1] = (int64_t)dwork_l.size();
@@ -1325,6 +1362,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->d_dwork_e = (DenseWork*)ddw;
       if ((st = upload(sym, D, dwork_l, &ddw)) != SCILMM_OK) return st;
       D->d_dwork_l = (DenseWork*)ddw;
+      if (getenv("SCILMM_VERBOSE") && dense_pairs_all > 0)
+        fprintf(stderr, "[scilmm plan] dense tail: %lld of %lld (target, descendant) panel pairs carry true entries (the others are padding only and skipped)\n",
+                (long long)dense_pairs_kept, (long long)dense_pairs_all);
       if (getenv("SCILMM_VERBOSE"))
         fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d%s)\n",
                 S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,

@@ -848,6 +848,17 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
           t = t2;
         }
       }
+      // block pattern of the true structure (which later tail fronts does a tail front reach at all)
+      S->tail_blk_ptr.assign((size_t)(ns - best) + 1, 0);
+      for (int32_t q = best; q < ns; ++q) {
+        const int64_t rb = S->sn_rowptr[q] + (out[q].end - out[q].start), re = S->sn_rowptr[q + 1];
+        int32_t last = -1;
+        for (int64_t t = rb; t < re; ++t) {
+          const int32_t f = snode_of[S->sn_rows[t]];  // rows ascending => fronts ascending
+          if (f != last) { S->tail_blk.push_back(f - best); last = f; }
+        }
+        S->tail_blk_ptr[(size_t)(q - best) + 1] = (int64_t)S->tail_blk.size();
+      }
       S->update_flops_pad = -true_tail;  // completed in step 10: executed(tail) - true(tail)
       S->dense_flops = true_tail;
       S->dense_first = best;

@@ -107,6 +107,11 @@ struct Symbolic {
   std::vector<int64_t> inv_off;    // [nsuper+1] offsets of the w x w inverse diagonal blocks
   // per input matrix k: for each stored lower entry (CSR order, j<=i) the pattern slot it lands in
   // (so values_upload can permute data_k into pattern order); empty for diagonal-only matrices
+  // dense tail, block pattern of the TRUE structure: tail front dense_first + d reaches (has at least one true row among
+  // the columns of) the tail fronts dense_first + tail_blk[tail_blk_ptr[d] .. tail_blk_ptr[d+1]) (ascending, all > d);
+  // its panel holds only padding at the columns of the others
+  std::vector<int64_t> tail_blk_ptr;
+  std::vector<int32_t> tail_blk;
   std::vector<std::vector<int64_t>> val_slot;   // [K][nnz_lower_k]
   std::vector<std::vector<int64_t>> val_src;    // [K][nnz_lower_k] index into data_k
   std::vector<uint8_t> is_diag;                 // [K] matrix k has a diagonal-only pattern

@@ -241,3 +241,31 @@ def test_large_sparse_graph_blocks_of_the_analysis_agree_with_the_plain_path():
     assert np.array_equal(A.data[r1[a]], T.data[r2[b]])
     rowof = np.repeat(np.arange(n), np.diff(A.indptr))
     assert (A.indices[r1] <= rowof[r1]).all()
+
+
+def test_tail_block_pattern_covers_the_true_structure():
+    """tail_blk lists, per dense-tail front, the later tail fronts it reaches: every block of the exact (boolean) Cholesky
+    structure that holds an entry must be listed -- the engine leaves the unlisted (target, descendant) pairs out."""
+    rng = np.random.default_rng(3)
+    seen_tail = skipped = 0
+    for trial in range(10):
+        n = int(rng.integers(150, 320))
+        M = random_spd(n, float(rng.uniform(0.02, 0.08)), 300 + trial)
+        sym = Symbolic([M, sp.identity(n, format="csr")], upload=False, max_width=8)
+        df, ns = int(sym.get("dense_first")[0]), sym.info().nsuper
+        if df >= ns:
+            continue
+        seen_tail += 1
+        S = _boolean_cholesky(M, sym.get("perm"))
+        st, bp, blk = sym.get("sn_start"), sym.get("tail_blk_ptr"), sym.get("tail_blk")
+        assert bp.size == ns - df + 1
+        for d in range(ns - df):
+            lst = blk[bp[d]:bp[d + 1]]
+            assert np.all(np.diff(lst) > 0) and (lst.size == 0 or lst[0] > d) and (lst.size == 0 or lst[-1] < ns - df)
+            cd = slice(st[df + d], st[df + d + 1])
+            for f in range(d + 1, ns - df):
+                if S[st[df + f]:st[df + f + 1], cd].any():
+                    assert f in lst
+                elif f not in lst:
+                    skipped += 1
+    assert seen_tail >= 3 and skipped > 0
