@@ -216,9 +216,10 @@ def test_moved_dense_tail_matches_oracle(monkeypatch, env):
     A, _ = small_pedigree(20000, 0.01, 1)
     n = A.shape[0]
     sym = _engine([A, sp.identity(n, format="csr")])
-    st = sym.get("sn_start")
-    ref = _engine([A, sp.identity(n, format="csr")], upload=False, perm=sym.get("perm"), dense_relax=-1.0)
-    assert not np.array_equal(st, ref.get("sn_start"))  # the case really is a moved tail (see test_symbolic.py)
+    base = _engine([A, sp.identity(n, format="csr")], upload=False, dense_relax=-1.0)  # no tail: the plain order
+    assert not np.array_equal(base.get("perm"), sym.get("perm"))  # the case really is a moved tail
+    bp = sym.get("tail_blk_ptr")
+    assert sym.get("tail_blk").size < (bp.size - 1) * (bp.size - 2) // 2  # ... with padding-only blocks to skip
     _check_factor([A, sp.identity(n, format="csr")], [0.35, 0.65], sym, rs=(5, 103))
 
 
