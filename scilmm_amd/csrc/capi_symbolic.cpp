@@ -31,6 +31,9 @@ int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, c
     if (opts->nd_oksep > 0) o.nd_oksep = opts->nd_oksep;
     if (opts->dense_relax != 0) o.dense_relax = o.dense_relax_wide = opts->dense_relax < 0 ? 0.0 : opts->dense_relax;  // explicit: one budget
   }
+  if (const char* t = getenv("SCILMM_TUNING"))
+    if (t[0] == '1')
+      if (const char* e = getenv("SCILMM_TAIL_WIDE")) o.dense_relax_wide = atof(e);  // flop budget of a wide tail
   if (perm_in && !opts) o.ordering = 2;
   scilmm_symbolic* h = new scilmm_symbolic();
   h->S = scilmm::symbolic_analyze(n, K, indptr, indices, perm_in, o);

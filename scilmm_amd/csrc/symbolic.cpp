@@ -659,6 +659,9 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
     int64_t cols_after = 0, best_cols = 0, wide_cols = 0;
     double best_ratio = 0.0, wide_ratio = 0.0;
     size_t nbest = 0, nwide = 0;
+    const char* tun = getenv("SCILMM_TUNING");
+    const char* eel = (tun && tun[0] == '1') ? getenv("SCILMM_TAIL_ELIG") : nullptr;
+    const double tail_elig = eel ? atof(eel) : 0.5;
     FILE* tail_dump = getenv("SCILMM_TAIL_DUMP") ? fopen(getenv("SCILMM_TAIL_DUMP"), "w") : nullptr;  // diagnostic: every candidate
     if (tail_dump) fprintf(tail_dump, "taken,front,w,true_rows,padded_rows,fl_dense_before,fl_true_before\n");
     while (!heap.empty()) {
@@ -666,14 +669,17 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       heap.pop();
       const double w = out[q].end - out[q].start, mt = (double)(S->sn_rowptr[q + 1] - S->sn_rowptr[q]), md = (double)cols_after + w;
       if (tail_dump) fprintf(tail_dump, "%d,%d,%.0f,%.0f,%.0f,%.6g,%.6g\n", (int)taken.size(), q, w, mt, md, fl_dense, fl_true);
-      if (2.0 * mt < md) continue;  // its list only gets relatively shorter as T grows: never eligible again
+      // (0.5: padding such a front costs at most 4 x its true flops, the ratio between the dense and the gather kernel.
+      // SCILMM_TUNING=1 SCILMM_TAIL_ELIG=x: at 1M 0.3 takes 27 more fronts, starts the tail 4 levels earlier -- fewer
+      // fronts behind k_outside, 7 x the cells -- and is slower, 30.2 vs 29.6 s.)
+      if (mt < tail_elig * md) continue;  // its list only gets relatively shorter as T grows: never eligible again
       fl_dense += w * md * md;
       fl_true += w * mt * mt;
       taken.push_back(q);
       cols_after += (int64_t)w;
       if (fl_dense <= opts.dense_relax * fl_true) { nbest = taken.size(); best_cols = cols_after; best_ratio = fl_dense / fl_true; }
       if (fl_dense <= opts.dense_relax_wide * fl_true) { nwide = taken.size(); wide_cols = cols_after; wide_ratio = fl_dense / fl_true; }
-      if (fl_dense > 1.5 * fl_true) break;
+      if (fl_dense > std::max(1.5, opts.dense_relax_wide) * fl_true) break;
       for (int32_t c = chead[q]; c != -1; c = cnext[c]) heap.push({S->sn_rowptr[c + 1] - S->sn_rowptr[c], c});
     }
     if (tail_dump) fclose(tail_dump);
@@ -885,6 +891,15 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
   for (int32_t s = 0; s < ns; ++s) {
     int32_t p = S->sn_parent[s];
     if (p != -1) S->sn_level[p] = std::max(S->sn_level[p], S->sn_level[s] + 1);
+  }
+  // (SCILMM_TUNING=1 SCILMM_TAIL_DELAY=k starts the tail chain k levels later, so that more of the prelude lies below
+  // it and goes through k_outside instead of the gather path: at 1M k = 24 moves 96 % of the remaining gather combos
+  // there, 2.8M -> 6.5M outside items, and the factorization takes the same 29.6 s -- the two paths cost the same.)
+  if (const char* e = (getenv("SCILMM_TUNING") && getenv("SCILMM_TUNING")[0] == '1') ? getenv("SCILMM_TAIL_DELAY") : nullptr) {
+    if (S->dense_first < ns) {
+      S->sn_level[S->dense_first] += atoi(e);
+      for (int32_t q = S->dense_first + 1; q < ns; ++q) S->sn_level[q] = std::max(S->sn_level[q], S->sn_level[q - 1] + 1);
+    }
   }
   S->nlevels = 0;
   for (int32_t s = 0; s < ns; ++s) S->nlevels = std::max(S->nlevels, S->sn_level[s] + 1);
