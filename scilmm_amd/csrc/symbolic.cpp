@@ -621,6 +621,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       tmp.clear();
     }
   }
+  lap("row structures");
   // ---------------------------------------------------------------- 7a. dense tail: which fronts
   // The top of a pedigree factor (16.6k columns at the 100k config, 170k at 1M; > 75 % / > 99 % of the flops) consists
   // of fronts whose row lists are "almost every later column".  Padding those lists to EVERY later column (explicit
@@ -876,7 +877,7 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
       }
     }
   }
-  lap("row structures");
+  lap("dense tail padding");
   // ---------------------------------------------------------------- 8. panel offsets, levels
   S->sn_loff.assign(ns + 1, 0);
   for (int32_t s = 0; s < ns; ++s) {
