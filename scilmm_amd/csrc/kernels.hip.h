@@ -1129,6 +1129,10 @@ __global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first,
 // after the barrier that retired that buffer's readers and lands while the MFMAs of chunk c run; one vmcnt(0) +
 // barrier per chunk.  k-rows past the end of a descendant are sourced from a zero page (`zeros`, >= 1 KiB), rows /
 // columns past the item's edge from row / column 0 (their accumulators are never stored).
+// (Measured and dropped: spreading the six DMA issues of a wave behind the MFMAs of the four k-steps instead of ahead
+// of them -- with the builtin hipcc drains the DMA before the next fragment read, 19.8 instead of 56.6 TFLOP/s alone;
+// from an asm statement, which it does not count, the statement's memory clobber still stops the fragment reads of
+// the next k-step from moving above it, 28.8 TFLOP/s.  The asm form issued in one go equals the builtin.)
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gl_vptr;
 __global__ __launch_bounds__(512, 1) void k_dense_g(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
