@@ -148,6 +148,20 @@ int scilmm_set_front_precision(scilmm_symbolic* sym, int32_t bits);
  * from the value arrays already resident in HBM (one streaming pass).  y'A_k y comes from scilmm_quadforms. */
 int scilmm_he_moments(scilmm_symbolic* sym, int32_t k1, int32_t k2, double* frob, double* diag_dot);
 
+/* Dominance relationship matrix on the pattern of the IBD matrix, built on the device (replaces
+ * reference scilmm/Matrices/Dominance.py:12-43 `dominance(rel, ibd)`):
+ *   out[t] = 1/4 (A[f_i,f_j] A[m_i,m_j] + A[f_i,m_j] A[m_i,f_j])  for the stored entry t = (i, j), i != j;  1 on the diagonal.
+ * A: CSR with both halves stored, rows strictly ascending (canonical), explicit zeros removed (the reference calls
+ * eliminate_zeros first); parents: n x 2 int32, -1 = unknown (contributes 0).  out has A's layout (same indptr /
+ * indices).  Values equal the reference's NumPy arithmetic bit for bit (no fma contraction).
+ * scilmm_dominance takes host buffers (upload, one kernel, download); scilmm_dominance_dev device buffers and a HIP
+ * stream (0 = default) and only enqueues.  scilmm_dominance_error(): text of the calling thread's last failure. */
+int scilmm_dominance(int32_t n, const int64_t* indptr, const int32_t* indices, const double* data, const int32_t* parents,
+                     double* out);
+int scilmm_dominance_dev(int32_t n, const int64_t* d_indptr, const int32_t* d_indices, const double* d_data,
+                         const int32_t* d_parents, double* d_out, void* stream);
+const char* scilmm_dominance_error(void);
+
 /* --- device-pointer variants used by bench.py and by callers that keep data resident in HBM */
 int scilmm_solve_dev(scilmm_factor* fac, const double* dB, int32_t r, double* dX);
 int scilmm_lmul_dev(scilmm_factor* fac, const double* dR, int32_t r, double* dZ);

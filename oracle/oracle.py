@@ -288,3 +288,37 @@ class SupernodalCPU(object):
         X = np.empty((self.n, Y.shape[1]))
         X[perm] = Y
         return X.reshape(B.shape)
+
+
+def dominance(parents, A):
+    """CPU restatement of reference scilmm/Matrices/Dominance.py:12-43 (test infrastructure, like everything here).
+
+    D_ij = 0.25 * (A[f_i,f_j] * A[m_i,m_j] + A[f_i,m_j] * A[m_i,f_j]) on the stored pattern of A (explicit zeros removed
+    first, :14), unit diagonal (:41-42); an unknown parent (-1) indexes the reference's all-zero root row (:17-24) and
+    contributes 0.  Same operation order as the reference's NumPy expression (:28-32), so the values are its bits.
+    """
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A).copy()
+    A.eliminate_zeros()
+    A.sort_indices()
+    n = A.shape[0]
+    par = np.asarray(parents).reshape(n, 2).astype(np.int64)
+    ii = np.repeat(np.arange(n, dtype=np.int64), np.diff(A.indptr))
+    jj = A.indices.astype(np.int64)
+    keys = ii * n + jj  # ascending: rows ascending, columns ascending inside a row
+
+    def look(r, c):
+        out = np.zeros(r.size)
+        ok = (r >= 0) & (c >= 0)
+        k = r[ok] * n + c[ok]
+        pos = np.minimum(np.searchsorted(keys, k), keys.size - 1)
+        out[ok] = np.where(keys[pos] == k, A.data[pos], 0.0)
+        return out
+
+    fi, mi, fj, mj = par[ii, 0], par[ii, 1], par[jj, 0], par[jj, 1]
+    vals = look(fi, fj) * look(mi, mj) + look(fi, mj) * look(mi, fj)
+    vals *= 0.25
+    vals[ii == jj] = 1.0
+    D = sp.csr_matrix((vals, A.indices.copy(), A.indptr.copy()), shape=A.shape)
+    D.eliminate_zeros()  # the reference's closing sparse arithmetic (:41-43) drops the entries that came out as 0
+    return D

@@ -67,6 +67,7 @@ SYMBOLS = [
     "scilmm_order", "scilmm_fill_count",
     "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments", "scilmm_set_front_precision",
     "scilmm_mm_read", "scilmm_mm_export", "scilmm_mm_error", "scilmm_mm_free",
+    "scilmm_dominance", "scilmm_dominance_dev", "scilmm_dominance_error",
 ]
 
 _lib = None
@@ -126,6 +127,9 @@ def lib():
     L.scilmm_dist_init.argtypes = [vp, i32, i32, vp, vp, vp]
     L.scilmm_factor_sizes.argtypes = [vp, P(i64), P(i64), P(i64)]
     L.scilmm_factor_create_external.argtypes = [vp, vp, vp, vp, P(vp)]
+    L.scilmm_dominance.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.scilmm_dominance_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.scilmm_dominance_error.restype = C.c_char_p
     L.scilmm_order.argtypes = [i32, vp, vp, i32, vp]
     L.scilmm_fill_count.argtypes = [i32, vp, vp, vp, P(i64), P(dbl), P(i32)]
     _lib = L
@@ -204,3 +208,24 @@ def read_matrix_market(path):
     finally:
         lib().scilmm_mm_free(h)
     return sp.csr_matrix((data, indices, indptr), shape=(nr.value, nc.value))
+
+
+def dominance(A, parents):
+    """Dominance relationship matrix on the pattern of the IBD matrix A (scipy CSR, both halves), built on the device
+    (include/scilmm_hip.h scilmm_dominance).  parents: (n, 2) int array, -1 = unknown.  Returns a CSR matrix that shares
+    A's pattern.  No CPU fallback."""
+    import scipy.sparse as sp
+    A = A.tocsr()
+    if not A.has_sorted_indices:
+        A = A.sorted_indices()
+    A.eliminate_zeros()
+    n = A.shape[0]
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    data = np.ascontiguousarray(A.data, dtype=np.float64)
+    par = np.ascontiguousarray(np.asarray(parents).reshape(n, 2), dtype=np.int32)
+    out = np.empty_like(data)
+    st = lib().scilmm_dominance(n, ptr(indptr), ptr(indices), ptr(data), ptr(par), ptr(out))
+    if st != OK:
+        raise ScilmmError("scilmm_dominance failed (%d): %s" % (st, (lib().scilmm_dominance_error() or b"").decode()))
+    return sp.csr_matrix((out, A.indices.copy(), A.indptr.copy()), shape=A.shape)

@@ -156,3 +156,21 @@ def test_product_lmm_with_oracle_factor_reproduces_reference_K3():
     assert rel_err(res["covariates coefficients"], g2["beta"]) < 1e-5
     assert rel_err(res["covariance std"], g2["std"]) < 1e-4
     assert rel_err(res["covariates p-values"], g2["pvalues"]) < 1e-5
+
+
+def test_dominance_restatement_matches_the_reference_golden():
+    """oracle.dominance against the dominance matrix the reference's own code produced (tests/golden/G2, made by
+    oracle/make_golden.py from scilmm.Matrices.Dominance.dominance): same pattern, same values to the last bit."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g1 = np.load(os.path.join(gold, "G1_reml_2000.npz"))
+    g2 = np.load(os.path.join(gold, "G2_lmm_dominance.npz"))
+    shape = tuple(g1["A_shape"])
+    A = sp.csr_matrix((g1["A_data"], g1["A_indices"], g1["A_indptr"]), shape=shape)
+    rel = sp.csr_matrix((g2["rel_data"], g2["rel_indices"], g2["rel_indptr"]), shape=shape)
+    Dref = sp.csr_matrix((g2["D_data"], g2["D_indices"], g2["D_indptr"]), shape=shape)
+    Dref.sort_indices()
+    from scilmm_amd.Matrices.Dominance import parents_of
+    Dm = O.dominance(parents_of(rel), A)
+    assert np.array_equal(Dm.indptr, Dref.indptr) and np.array_equal(Dm.indices, Dref.indices)
+    assert np.array_equal(Dm.data, Dref.data)
