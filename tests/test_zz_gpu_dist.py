@@ -32,9 +32,10 @@ def _problem():
     return [A, sp.eye(n).tocsr()], C, y
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, env):
     import faulthandler
     faulthandler.dump_traceback_later(240, exit=True)  # a stuck collective must not leave a process on the GPU
+    os.environ.update(env)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,12 +57,16 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_process(tmp_path):
+@pytest.mark.parametrize("env", [{}, {"SCILMM_TUNING": "1", "SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1"}],
+                         ids=["default", "dense+outside"])
+def test_two_ranks_one_gpu_match_single_process(tmp_path, env):
+    """env 2 forces, at this small size, the schedule the 300k / 1M configurations get by default on every rank of a
+    multi-GPU run: dense-tail kernel + atomic prelude -> tail contributions, restricted to the panels a rank owns."""
     import torch.multiprocessing as mp
     from oracle import reml_oracle as RO
     from scilmm_amd.factor import Symbolic
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, env), nprocs=2, join=True)
     got = [np.load(out % r) for r in range(2)]
     mats, C, y = _problem()
     sym = Symbolic(mats)
