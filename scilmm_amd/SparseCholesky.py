@@ -53,13 +53,18 @@ class SparseCholesky(object):
     x2 at 30k), and the analysis runs once per pattern either way.
     """
 
-    def __init__(self, use_long=False, mode='supernodal', ordering_method='default', perm=None, fused=True):
+    def __init__(self, use_long=False, mode='supernodal', ordering_method='default', perm=None, fused=True,
+                 exact_trace=False):
         _lib.lib()  # fail loudly when the HIP library is not built
         self._use_long = use_long
         self._mode = mode
         self._ordering_method = ordering_method
         self._perm = perm
         self.fused = fused
+        # opt-in (SURVEY 8f rank 4): tr(V^-1 A_k) of the gradient computed exactly instead of by the reference's
+        # Monte-Carlo estimate (SparseCholesky.py:49-52, :65) -- see _exact_traces.  Default off: the default
+        # behaviour has to be the reference's stochastic estimator.
+        self.exact_trace = exact_trace
         self._cache = {}
 
     def _ordering(self):
@@ -173,6 +178,33 @@ def _polar_columns(c):
     return pairs
 
 
+EXACT_TRACE_MAX_N = 200000
+EXACT_TRACE_BLOCK = 512
+
+
+def _exact_traces(fac, mats):
+    """tr(V^-1 A_k) for every k, exactly: V^-1 E_b for blocks E_b of identity columns (one multi-right-hand-side sweep
+    of the device factor per block), contracted with the matching columns of A_k.  n / EXACT_TRACE_BLOCK sweeps and
+    n^2 doubles over PCIe per evaluation: the brute-force form, meant for n up to ~1e5 (8 s per evaluation at the 100k
+    config); the scalable form -- a selected inverse on the supernodal factor (Takahashi) -- is not built.  Removes
+    the random vectors, and with them np.random, from the objective."""
+    n = fac.n
+    if n > EXACT_TRACE_MAX_N:
+        raise ValueError("exact_trace is the brute-force form (n / %d factor sweeps per evaluation): n = %d is beyond its "
+                         "limit of %d" % (EXACT_TRACE_BLOCK, n, EXACT_TRACE_MAX_N))
+    cscs = [sparse.csc_matrix(m) for m in mats]
+    tr = np.zeros(len(mats))
+    for b0 in range(0, n, EXACT_TRACE_BLOCK):
+        b1 = min(n, b0 + EXACT_TRACE_BLOCK)
+        E = np.zeros((n, b1 - b0))
+        E[np.arange(b0, b1), np.arange(b1 - b0)] = 1.0
+        X = fac(E)
+        for k, m in enumerate(cscs):
+            blk = m[:, b0:b1]
+            tr[k] += float(blk.multiply(X).sum())
+    return tr
+
+
 def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num):
     """One likelihood + gradient evaluation on the device (fused form of SparseCholesky.py:88-109)."""
     sym = cholesky_func.engine_for(mats)
@@ -180,7 +212,17 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
     fac = state.get(id(sym))
     n = y.size
     c = covariates.shape[1]
-    if fac is None:
+    exact = bool(getattr(cholesky_func, 'exact_trace', False))
+    if exact:
+        # no random vectors: factorize, solve for [C | y], exact traces
+        if fac is None:
+            state.clear()
+            fac = state[id(sym)] = sym.factorize(sig2g_array)
+        else:
+            fac.refactorize(sig2g_array)
+        sim_num = 0
+        Z = np.zeros((n, 0))
+    elif fac is None:
         state.clear()
         fac = state[id(sym)] = sym.factorize(sig2g_array)
         R = np.random.randn(n, sim_num)
@@ -190,7 +232,8 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
         fac.refactorize_async(sig2g_array)
         R = np.random.randn(n, sim_num)
         fac.wait()
-    Z = fac.lmul(R)
+    if not exact:
+        Z = fac.lmul(R)
     if cholesky_func.fused:
         X = fac(np.hstack([covariates, y[:, None], Z]))
         invV_C, invV_y0, U = X[:, :c], X[:, c], X[:, c + 1:]
@@ -201,7 +244,7 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
     else:
         invV_C, L_CT_invV_C, mu, beta = estimate_fixed_effects(fac, y, covariates)
         invV_y = fac(y - mu)
-        U = fac(Z)
+        U = fac(Z) if Z.shape[1] else Z
     nll = negative_log_likelihood(fac, y, invV_y, mu, L_CT_invV_C, reml)
     # gradient: one fused SpMM+reduce per matrix over [U | v | C-columns and pairwise sums]
     cols = [U, invV_y[:, None]]
@@ -212,9 +255,10 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
             cols.append((invV_C[:, a] + invV_C[:, b])[:, None])
     Q = np.ascontiguousarray(np.hstack(cols))
     grad = np.zeros(len(sig2g_array))
+    traces = _exact_traces(fac, mats) if exact else None
     for k in range(len(sig2g_array)):
         q = sym.quadforms(k, Q)
-        grad[k] = 0.5 * (np.mean(q[:sim_num]) - q[sim_num])
+        grad[k] = 0.5 * ((traces[k] if exact else np.mean(q[:sim_num])) - q[sim_num])
         if reml:
             M = np.zeros((c, c))
             d = q[sim_num + 1: sim_num + 1 + c]

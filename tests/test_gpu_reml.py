@@ -190,3 +190,45 @@ def test_he_moments_on_device_match_host():
     assert abs(dg - A.diagonal().dot(D.diagonal())) < 1e-12 * abs(dg)
     fro_i, dg_i = sym.he_moments(0, 2)   # against the (diagonal-only) identity: the trace of A
     assert abs(fro_i - A.diagonal().sum()) < 1e-12 * abs(fro_i) and abs(dg_i - fro_i) < 1e-12 * abs(fro_i)
+
+
+def test_exact_trace_option_gives_the_analytic_gradient():
+    """exact_trace=True (opt-in): tr(V^-1 A_k) by blocked identity solves instead of the Monte-Carlo
+    estimate -- equal to the dense inverse's trace, gradient = central finite difference of the (now deterministic)
+    objective, REML result independent of the np.random seed; the default path still draws its random vectors."""
+    M = importlib.import_module("scilmm_amd.SparseCholesky")  # (the package attribute of that name is the class)
+    from scilmm_amd.harness import pedigree as H
+    mats, C, y = H.make_problem(2500, 0.01, seed=4, with_dominance=True)
+    mats = mats + [sp.identity(y.size, format="csr")]
+    n = y.size
+    chol = M.SparseCholesky(exact_trace=True)
+    x0 = np.log(np.array([0.3, 0.2, 0.5]))
+    np.random.seed(1)
+    state = np.random.get_state()[1].copy()
+    nll, g = M.bolt_gradient_estimation(x0, chol, mats, C, y, True, 100, False)
+    assert np.array_equal(np.random.get_state()[1], state)  # no random numbers consumed
+    V = sum(s * m for s, m in zip(np.exp(x0), mats)).toarray()
+    Vi = np.linalg.inv(V)
+    fac = chol._factor_state[id(chol.engine_for(mats))]
+    tr = M._exact_traces(fac, mats)
+    for k, m in enumerate(mats):
+        assert abs(tr[k] - np.sum(Vi * m.toarray())) < 1e-9 * abs(tr[k])
+    h = 1e-5
+    for k in range(3):
+        e = np.zeros(3)
+        e[k] = h
+        up = M.bolt_gradient_estimation(x0 + e, chol, mats, C, y, True, 100, False)[0]
+        dn = M.bolt_gradient_estimation(x0 - e, chol, mats, C, y, True, 100, False)[0]
+        assert abs((up - dn) / (2 * h) - g[k]) < 1e-5 * max(1.0, abs(g[k]))
+    res = []
+    for seed in (0, 123):
+        np.random.seed(seed)
+        # (REML appends the identity itself, SparseCholesky.py:178)
+        res.append(M.REML(M.SparseCholesky(exact_trace=True), mats[:-1], C, y, verbose=False)["covariance coefficients"])
+    assert rel_err(res[0], res[1]) < 1e-8  # (to rounding: the chain sweeps of the solves sum in arrival order)
+    with pytest.raises(ValueError):
+        M.EXACT_TRACE_MAX_N, keep = 10, M.EXACT_TRACE_MAX_N
+        try:
+            M.bolt_gradient_estimation(x0, chol, mats, C, y, True, 100, False)
+        finally:
+            M.EXACT_TRACE_MAX_N = keep
