@@ -126,7 +126,8 @@ struct Dev {
   bool dense_on = false;
   int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
   int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
-  int dense_glds = 1;                   // staging of the 16x16x4 form: 1 = LDS-DMA (k_dense_g), 0 = through registers (k_dense)
+  int dense_glds = 2;                   // 16x16x4 form: 2 = A fragments from registers, B 64 deep by LDS-DMA (k_dense_a),
+                                        // 1 = both operands by LDS-DMA (k_dense_g), 0 = staged through registers (k_dense)
   double* d_zeros = nullptr;            // 2 KiB of zeros: source of the k-rows past a descendant's end (k_dense_g)
   DenseWork* d_dwork_e = nullptr;
   DenseWork* d_dwork_l = nullptr;
@@ -557,7 +558,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* emf = tune_env("SCILMM_DENSE_MF");
     if (emf) D->dense_mf = atoi(emf) == 4 ? 4 : 16;
     const char* egl = tune_env("SCILMM_DENSE_GLDS");
-    if (egl) D->dense_glds = egl[0] != '0';
+    if (egl) D->dense_glds = egl[0] == '0' ? 0 : egl[0] == '1' ? 1 : 2;
     if (D->dense_on && !D->d_zeros) {
       HIPCHK(hipMalloc((void**)&D->d_zeros, 2048));
       HIPCHK(hipMemset(D->d_zeros, 0, 2048));
@@ -1369,7 +1370,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d%s)\n",
                 S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,
                 (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels], D->dense_mf,
-                D->dense_mf == 16 && D->dense_glds ? ", LDS-DMA staging" : "");
+                D->dense_mf != 16 ? "" : D->dense_glds == 2 ? ", A from registers, B by LDS-DMA" : D->dense_glds ? ", LDS-DMA staging" : "");
     }
     if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
     {
@@ -1585,6 +1586,7 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense_g, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1749,6 +1751,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       hipLaunchKernelGGL((k_dense<4, false>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
     else if (D->dense_mf == 4)
       hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
+    else if (D->dense_glds == 2)
+      hipLaunchKernelGGL(k_dense_a, dim3((unsigned)cnt), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw,
+                         fac->L, scratch_half, (const double*)D->d_zeros);
     else if (D->dense_glds)
       hipLaunchKernelGGL(k_dense_g, dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half,
                          (const double*)D->d_zeros);

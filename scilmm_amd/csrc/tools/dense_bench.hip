@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_dense_g, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_dense_a, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   double* zeros;
   CK(hipMalloc(&zeros, 2048));
   CK(hipMemset(zeros, 0, 2048));
@@ -73,7 +74,7 @@ int main(int argc, char** argv) {
   printf("T=%d panels, target %d: %zu items (%d descendants each), %.3f TFLOP per launch, %.1f MB of slabs\n", T, j, work.size(), per,
          flops / 1e12, slot * TM * NB * 8 / 1e6);
   for (int fill : {0, 1})
-  for (int mf : {16, 160, 4, 32}) {
+  for (int mf : {16, 160, 170}) {
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, (size_t)sn_loff[T], fill);
     for (int rep = 0; rep < 3; ++rep) {
       unsigned long long z[2] = {0, 0};
@@ -81,6 +82,7 @@ int main(int argc, char** argv) {
       hipEventRecord(e0);
       if (mf == 16) hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
       else if (mf == 160) hipLaunchKernelGGL(k_dense_g, dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      else if (mf == 170) hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), sizeof(double) * 2 * KBA * LDB, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else if (mf == 4) hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
       else hipLaunchKernelGGL(k_dense32, dim3((unsigned)work.size()), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), 0, S, 0, d_work, L, scratch);
       hipEventRecord(e1);
@@ -89,7 +91,8 @@ int main(int argc, char** argv) {
       hipEventElapsedTime(&ms, e0, e1);
       CK(hipGetLastError());
       CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_dense_clk), sizeof(z)));
-      if (rep && mf == 160) printf("k_dense_g (LDS-DMA staging), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
+      if (rep && mf == 170) printf("k_dense_a (A from registers, B 64 deep by LDS-DMA), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
+      else if (rep && mf == 160) printf("k_dense_g (LDS-DMA staging), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
       else if (rep && mf != 32) printf("k_dense<%d>, %s operands: %.3f ms -> %.2f TFLOP/s at %.2f GHz shader clock\n", mf, fill ? "random" : "zero", ms,
                       flops / ms / 1e9, 0.1 * (double)z[1] / (double)z[0]);
       if (rep && mf == 32) printf("k_dense32 (fp32 products, fp64 sums), %s operands: %.3f ms -> %.2f TFLOP/s\n", fill ? "random" : "zero", ms, flops / ms / 1e9);
@@ -104,11 +107,11 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch);
     CK(hipMemcpy(r0.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
     CK(hipMemset(scratch, 0, sizeof(double) * ns));
-    hipLaunchKernelGGL(k_dense_g, dim3((unsigned)work.size()), dim3(512), sm, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+    hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), sizeof(double) * 2 * KBA * LDB, 0, S, 0, d_work, L, scratch, (const double*)zeros);
     CK(hipMemcpy(r1.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
     double mx = 0, ref = 0;
     for (size_t i = 0; i < ns; ++i) { mx = std::max(mx, std::fabs(r0[i] - r1[i])); ref = std::max(ref, std::fabs(r0[i])); }
-    printf("k_dense_g vs k_dense<16>: max |difference| of the slabs %.3g (largest entry %.3g)\n", mx, ref);
+    printf("k_dense_a vs k_dense<16>: max |difference| of the slabs %.3g (largest entry %.3g)\n", mx, ref);
   }
   return 0;
 }

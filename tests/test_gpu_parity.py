@@ -206,7 +206,8 @@ def test_alternative_schedules_agree_with_oracle(monkeypatch, env):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{}, {"SCILMM_DENSE": "1"}, {"SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1"},
-                                 {"SCILMM_OUTSIDE": "1"}, {"SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1", "SCILMM_DENSE_GLDS": "0"}])
+                                 {"SCILMM_OUTSIDE": "1"}, {"SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1", "SCILMM_DENSE_GLDS": "0"},
+                                 {"SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1", "SCILMM_DENSE_GLDS": "1"}])
 def test_moved_dense_tail_matches_oracle(monkeypatch, env):
     """A pedigree whose dense tail is NOT a chain of the elimination tree (a side branch of near-dense fronts joins it
     and the tail is moved to the end of the order; symbolic.cpp step 7a): every schedule must match the oracle."""
