@@ -1240,6 +1240,10 @@ __global__ __launch_bounds__(512, 1) void k_dense_g(DevSym S, int32_t dense_firs
 // LDS-DMA as in k_dense_g: one barrier per 64 k instead of per 16, no A image to write or read.  Same items, slabs,
 // epilogue and summation order as k_dense (bit-identical results).
 constexpr int KBA = 64;  // depth of a B buffer of k_dense_a
+#ifndef SCILMM_DENSE_A_SCHED
+#define SCILMM_DENSE_A_SCHED 0  // tuning harness: 0 = scheduling barrier after every k-step, 1 = after every sub-chunk, 2 = every 2 k-steps
+                                // (alone, zero / random operands: 61.6 / 59.5, 61.0 / 58.6, 61.6 / 57.9 TFLOP/s -- no difference)
+#endif
 __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
                                                     double* __restrict__ L, double* __restrict__ scratch,
                                                     const double* __restrict__ zeros) {
@@ -1313,26 +1317,36 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
         acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
         acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
       }
+#if SCILMM_DENSE_A_SCHED == 0
       __builtin_amdgcn_sched_barrier(0);  // keep the k-steps apart: unrolled 16 deep, the scheduler otherwise hoists every
                                           // fragment read to the top and spills 149 registers
+#endif
     };
     {
       // sub-chunk s + 1 (or sub-chunk 0 of the next chunk) is in flight while sub-chunk s is multiplied.  A chunk shorter
       // than 64 (last chunk of a descendant whose width is no multiple of 64 -- rare) runs the same 16 k-steps: its B
       // k-rows past the end are zero, its A loads re-read the last column.  (A separate rolled loop for it cost the
       // common path its registers: 156 spills.)
+#if SCILMM_DENSE_A_SCHED == 1
+#define SCILMM_SUBSYNC(q) if ((q) == 3) __builtin_amdgcn_sched_barrier(0)
+#elif SCILMM_DENSE_A_SCHED == 2
+#define SCILMM_SUBSYNC(q) if ((q) & 1) __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCILMM_SUBSYNC(q)
+#endif
       load_A(cur, 1, rA[1]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kstep(4 * q, rA[0][q][0], rA[0][q][1]);
+      for (int q = 0; q < 4; ++q) { kstep(4 * q, rA[0][q][0], rA[0][q][1]); SCILMM_SUBSYNC(q); }
       load_A(cur, 2, rA[0]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kstep(16 + 4 * q, rA[1][q][0], rA[1][q][1]);
+      for (int q = 0; q < 4; ++q) { kstep(16 + 4 * q, rA[1][q][0], rA[1][q][1]); SCILMM_SUBSYNC(q); }
       load_A(cur, 3, rA[1]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kstep(32 + 4 * q, rA[0][q][0], rA[0][q][1]);
+      for (int q = 0; q < 4; ++q) { kstep(32 + 4 * q, rA[0][q][0], rA[0][q][1]); SCILMM_SUBSYNC(q); }
       if (more) load_A(nxt, 0, rA[0]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kstep(48 + 4 * q, rA[1][q][0], rA[1][q][1]);
+      for (int q = 0; q < 4; ++q) { kstep(48 + 4 * q, rA[1][q][0], rA[1][q][1]); SCILMM_SUBSYNC(q); }
+#undef SCILMM_SUBSYNC
     }
     if (!more) break;
     cur = nxt;
