@@ -305,7 +305,7 @@ def main():
         if dense_on:
             # dominant kernel = k_dense: ITS algorithmic flops (tail x tail updates, true structure) over ITS launches
             kern = ("k_dense32 (fp32 products, fp64 sums: update of the dense tail by the dense tail)" if args.front_bits == 32 else
-                    "k_dense_g (fp64 MFMA update of the dense tail by the dense tail, LDS-DMA staging)")
+                    "k_dense_a (fp64 MFMA update of the dense tail by the dense tail: A fragments from registers, B by LDS-DMA)")
             flops_k, n_k, ms_k = info.dense_flops * K, prof["n_dense_launches"], prof["dense_ms"]
         else:
             kern = "k_update2<true> (fp64 MFMA supernodal update)"

@@ -24,7 +24,7 @@ def by_kernel(path):
 def main():
     workload, fpath, wpath, nfact, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     f, w = by_kernel(fpath), by_kernel(wpath)
-    upd = [k for k in f.index if k in ("k_dense", "k_dense_g", "k_update2", "k_update3", "k_update")]
+    upd = [k for k in f.index if k in ("k_dense", "k_dense_g", "k_dense_a", "k_update2", "k_update3", "k_update")]
     fetch_kb = float(f.loc[upd, "value"].sum()) / nfact
     write_kb = float(w.loc[[k for k in upd if k in w.index], "value"].sum()) / nfact
     launches = float(f.loc[upd, "dispatches"].sum()) / nfact
