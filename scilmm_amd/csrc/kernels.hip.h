@@ -1239,6 +1239,10 @@ __global__ __launch_bounds__(512, 1) void k_dense_g(DevSym S, int32_t dense_firs
 // ahead of their use.  LDS then holds B alone, 64 k-rows deep per buffer (2 x 64 x 144 doubles = 144 KB) and filled by
 // LDS-DMA as in k_dense_g: one barrier per 64 k instead of per 16, no A image to write or read.  Same items, slabs,
 // epilogue and summation order as k_dense (bit-identical results).
+#ifndef SCILMM_DENSE_A_ABL
+#define SCILMM_DENSE_A_ABL 0  // tuning harness only: 1 = A fragments loaded once per item (WRONG numbers; what do the loads cost?),
+                              // 2 = B copied once per item
+#endif
 constexpr int KBA = 64;  // depth of a B buffer of k_dense_a
 #ifndef SCILMM_DENSE_A_SCHED
 #define SCILMM_DENSE_A_SCHED 0  // tuning harness: 0 = scheduling barrier after every k-step, 1 = after every sub-chunk, 2 = every 2 k-steps
@@ -1263,6 +1267,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
   const double* zsrc = zeros + 2 * lane;
   struct Chunk { const double* Pd; int64_t md; int kc; };
   int32_t kd = wk.k0, kk0 = 0;
+  bool first_a = true, first_b = true;  // (only read by the tuning-harness ablations)
   auto next_chunk = [&]() {
     const int32_t d = dense_first + kd;
     const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
@@ -1275,6 +1280,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
     return c;
   };
   auto issue_B = [&](const Chunk& c, int b) {
+    if (SCILMM_DENSE_A_ABL == 2 && !first_b) return;
     double* Bs = smem + b * KBA * LDB;
 #pragma unroll
     for (int i = 0; i < KBA / 8; ++i) {
@@ -1283,6 +1289,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
     }
   };
   auto load_A = [&](const Chunk& c, int s, double (&ra)[4][2]) {
+    if (SCILMM_DENSE_A_ABL == 1 && !first_a) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double* p = c.Pd + (int64_t)min(16 * s + 4 * q + lk, c.kc - 1) * c.md;  // past the end: any valid column (B is 0 there)
@@ -1298,6 +1305,8 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
   Chunk cur = next_chunk();
   issue_B(cur, 0);
   load_A(cur, 0, rA[0]);
+  if (SCILMM_DENSE_A_ABL == 1) { load_A(cur, 1, rA[1]); first_a = false; }
+  first_b = false;
   __syncthreads();
   int buf = 0;
   while (true) {
