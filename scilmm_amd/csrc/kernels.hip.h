@@ -1239,6 +1239,8 @@ __global__ __launch_bounds__(512, 1) void k_dense_g(DevSym S, int32_t dense_firs
 // ahead of their use.  LDS then holds B alone, 64 k-rows deep per buffer (2 x 64 x 144 doubles = 144 KB) and filled by
 // LDS-DMA as in k_dense_g: one barrier per 64 k instead of per 16, no A image to write or read.  Same items, slabs,
 // epilogue and summation order as k_dense (bit-identical results).
+// (Measured and dropped: three register sets with the A loads TWO sub-chunks ahead -- 256 VGPRs, same 61.5 / 58.6
+// TFLOP/s alone: the loads cost issue and bandwidth, not latency.)
 #ifndef SCILMM_DENSE_A_ABL
 #define SCILMM_DENSE_A_ABL 0  // tuning harness only: 1 = A fragments loaded once per item (WRONG numbers; what do the loads cost?),
                               // 2 = B copied once per item
