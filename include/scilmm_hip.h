@@ -67,14 +67,22 @@ typedef struct scilmm_info {
 } scilmm_info;
 
 /* --- symbolic phase: replaces cholmod_analyze inside sk_cholesky (SparseCholesky.py:23-26), but once per
- * pattern instead of once per evaluation.  indptr[k]/indices[k] is the CSR pattern of mats[k]; only
- * entries with column <= row are read (the matrices are symmetric).  perm_in[new] = old or NULL. */
+ * pattern instead of once per evaluation.  indptr[k]/indices[k] is the CSR pattern of mats[k]; VALUES are only ever
+ * read from the entries with column <= row (the matrices are symmetric).  Inputs that store both halves with
+ * strictly ascending rows (what SciPy hands over) are analysed without any scatter pass -- verified by a hash of the
+ * mirrored entries; anything else (one half only, unsorted rows, an unsymmetric pattern, whose upper entries are
+ * ignored) takes a slower path with the same result.  perm_in[new] = old or NULL; a given permutation is used exactly
+ * as it is, otherwise the library's ordering may be followed by moving the dense tail's fronts to the end of the
+ * order (same fill). */
 int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const scilmm_options* opts, int32_t ngpus,
                            scilmm_symbolic** out);
 int scilmm_symbolic_info(const scilmm_symbolic* sym, scilmm_info* info);
 /* Copy a named int32/int64 array of the analysis ("perm" replaces factor.P(), SparseCholesky.py:93).
- * Call with out == NULL to get the element count. */
+ * Call with out == NULL to get the element count.  Names: perm, iperm, parent, colcount, sn_start, sn_parent,
+ * sn_rowptr, sn_rows, sn_loff, sn_level, level_ptr, level_fronts, dense_first, tail_blk_ptr / tail_blk (block pattern
+ * of the dense tail's true structure), asm_dst, diag_dst, pat_colptr, pat_row, val_slot:k / val_src:k (value-assembly
+ * maps of input matrix k), upd_*, tile_*, combo_* (built on demand), level_tile_*, level_pair_*, inv_off, child_*. */
 int scilmm_symbolic_get(const scilmm_symbolic* sym, const char* what, void* out, int64_t* count);
 const char* scilmm_symbolic_error(const scilmm_symbolic* sym);
 void scilmm_symbolic_free(scilmm_symbolic* sym);
