@@ -18,6 +18,7 @@ Any other callable obeying the factor protocol (``factor(b)``, ``.L()``, ``.P()`
 accepted as ``cholesky_func`` exactly as in the reference and takes the reference-shaped path; there is
 no silent fallback: constructing ``SparseCholesky()`` without the built HIP library raises.
 """
+import os
 import time
 
 import numpy as np
@@ -178,6 +179,74 @@ def _polar_columns(c):
     return pairs
 
 
+def _device_buffers():
+    """torch (device memory and copies only -- plumbing) if it can reach the GPU the engine runs on, else None: the
+    evaluation then goes through host buffers, same arithmetic, more PCIe traffic."""
+    if os.environ.get("SCILMM_HOST_BUFFERS") == "1":
+        return None
+    try:
+        import torch
+        return torch if torch.cuda.is_available() else None
+    except Exception:
+        return None
+
+
+def _finish_on_device(torch, sym, fac, R, sig2g_array, covariates, y, reml, sim_num):
+    """Everything after the factorization of one evaluation with the n x 100 blocks kept in HBM: R goes down once,
+    Z = P^T L R, the 103-column solve and the K fused SpMM + reduce calls read and write device buffers through the
+    `_dev` entry points, and only the c + 1 solution columns the host algebra needs (and the quadratic forms) come
+    back.  Same operations in the same order as the host-buffer path (fused form of SparseCholesky.py:88-109)."""
+    import ctypes
+    n, c = y.size, covariates.shape[1]
+    vp = ctypes.c_void_p
+    dR = torch.from_numpy(np.ascontiguousarray(R)).cuda()
+    dZ = torch.empty_like(dR)
+    torch.cuda.synchronize()
+    fac.lmul_dev(vp(dR.data_ptr()), sim_num, vp(dZ.data_ptr()))
+    sym.sync()
+    del dR
+    head = torch.from_numpy(np.ascontiguousarray(np.hstack([covariates, y[:, None]]))).cuda()
+    dB = torch.cat([head, dZ], dim=1).contiguous()
+    del dZ
+    dX = torch.empty_like(dB)
+    torch.cuda.synchronize()
+    fac.solve_dev(vp(dB.data_ptr()), c + 1 + sim_num, vp(dX.data_ptr()))
+    sym.sync()
+    del dB
+    Xh = dX[:, :c + 1].cpu().numpy()
+    invV_C, invV_y0 = Xh[:, :c], Xh[:, c]
+    L_CT_invV_C = la.cho_factor(covariates.T.dot(invV_C))
+    beta = la.cho_solve(L_CT_invV_C, covariates.T.dot(invV_y0))
+    mu = covariates.dot(beta)
+    invV_y = invV_y0 - invV_C.dot(beta)
+    nll = negative_log_likelihood(fac, y, invV_y, mu, L_CT_invV_C, reml)
+    tail = [invV_y[:, None]]
+    pairs = _polar_columns(c) if reml else []
+    if reml:
+        tail.append(invV_C)
+        for a, b in pairs:
+            tail.append((invV_C[:, a] + invV_C[:, b])[:, None])
+    dQ = torch.cat([dX[:, c + 1:], torch.from_numpy(np.ascontiguousarray(np.hstack(tail))).cuda()], dim=1).contiguous()
+    del dX
+    rq = dQ.shape[1]
+    dq = torch.empty(rq, dtype=torch.float64, device=dQ.device)
+    grad = np.zeros(len(sig2g_array))
+    for k in range(len(sig2g_array)):
+        torch.cuda.synchronize()
+        sym.quadforms_dev(k, vp(dQ.data_ptr()), rq, vp(dq.data_ptr()))
+        sym.sync()
+        q = dq.cpu().numpy()
+        grad[k] = 0.5 * (np.mean(q[:sim_num]) - q[sim_num])
+        if reml:
+            M = np.zeros((c, c))
+            d = q[sim_num + 1: sim_num + 1 + c]
+            M[np.arange(c), np.arange(c)] = d
+            for t, (a, b) in enumerate(pairs):
+                M[a, b] = M[b, a] = 0.5 * (q[sim_num + 1 + c + t] - d[a] - d[b])
+            grad[k] -= 0.5 * np.trace(la.cho_solve(L_CT_invV_C, M))
+    return nll, grad, fac
+
+
 EXACT_TRACE_MAX_N = 200000
 EXACT_TRACE_BLOCK = 512
 
@@ -232,6 +301,9 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
         fac.refactorize_async(sig2g_array)
         R = np.random.randn(n, sim_num)
         fac.wait()
+    dev = None if exact or not cholesky_func.fused or getattr(sym, "front_bits", 64) == 32 else _device_buffers()
+    if dev is not None:
+        return _finish_on_device(dev, sym, fac, R, sig2g_array, covariates, y, reml, sim_num)
     if not exact:
         Z = fac.lmul(R)
     if cholesky_func.fused:

@@ -232,3 +232,22 @@ def test_exact_trace_option_gives_the_analytic_gradient():
             M.bolt_gradient_estimation(x0, chol, mats, C, y, True, 100, False)
         finally:
             M.EXACT_TRACE_MAX_N = keep
+
+
+def test_device_resident_evaluation_equals_host_buffer_path(monkeypatch):
+    """The evaluation keeps its n x 100 blocks in HBM (torch buffers + the `_dev` entry points) when torch reaches the GPU;
+    SCILMM_HOST_BUFFERS=1 forces the host-buffer path.  Same operations, same np.random stream: same numbers."""
+    Pm = importlib.import_module("scilmm_amd.SparseCholesky")
+    from scilmm_amd.harness import pedigree as H
+    mats, C, y = H.make_problem(6000, 0.01, seed=2)
+    mats = mats + [sp.identity(y.size, format="csr")]
+    assert Pm._device_buffers() is not None
+    out = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("SCILMM_HOST_BUFFERS", host)
+        np.random.seed(7)
+        chol = Pm.SparseCholesky()
+        vals = [Pm.bolt_gradient_estimation(np.log([0.4, 0.6]) + 0.05 * i, chol, mats, C, y, True, 100, False) for i in range(2)]
+        out.append(vals)
+    for (n0, g0), (n1, g1) in zip(*out):
+        assert abs(n0 - n1) < 1e-12 * abs(n1) and rel_err(g0, g1) < 1e-10
