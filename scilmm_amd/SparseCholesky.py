@@ -182,7 +182,7 @@ def _polar_columns(c):
 def _device_buffers():
     """torch (device memory and copies only -- plumbing) if it can reach the GPU the engine runs on, else None: the
     evaluation then goes through host buffers, same arithmetic, more PCIe traffic."""
-    if os.environ.get("SCILMM_HOST_BUFFERS") == "1":
+    if os.environ.get("SCILMM_HOST_BUFFERS") == "1" or os.environ.get("SCILMM_NO_TORCH") == "1":
         return None
     try:
         import torch

@@ -81,6 +81,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ScilmmError("libscilmm_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (or make -C scilmm_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    # torch (device buffers of the REML evaluation, torch.distributed) ships its own copy of the HIP runtime: if this
+    # library pulled /opt/rocm's in first, a later `import torch` would find no GPU.  Loading torch first makes both
+    # sides share one runtime (the order bench.py always had).  SCILMM_NO_TORCH=1 skips it (host buffers only).
+    if os.environ.get("SCILMM_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     P = C.POINTER
