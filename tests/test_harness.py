@@ -110,3 +110,26 @@ def test_native_matrix_market_reader_matches_scipy(tmp_path):
     bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")
     with pytest.raises(_lib.ScilmmError):
         _lib.read_matrix_market(str(bad))
+
+
+def test_quick_id_sees_in_place_edits():
+    """The engine cache of the drop-in `SparseCholesky` keys on a full-pass checksum of the value arrays: an in-place
+    edit of one entry, a sign flip and a swap of two entries must all change it, identical content must not."""
+    import importlib
+    P = importlib.import_module("scilmm_amd.SparseCholesky")
+    rng = np.random.default_rng(0)
+    A = sp.random(300, 300, 0.05, random_state=1, format="csr") + sp.identity(300, format="csr")
+    A = A.tocsr()
+    mats = [A, sp.identity(300, format="csr")]
+    q0 = P.SparseCholesky._quick_id(mats)
+    assert P.SparseCholesky._quick_id(mats) == q0
+    k = int(rng.integers(1, A.nnz - 1))
+    keep = A.data[k]
+    A.data[k] = keep * 1.0000001
+    assert P.SparseCholesky._quick_id(mats) != q0
+    A.data[k] = -keep
+    assert P.SparseCholesky._quick_id(mats) != q0
+    A.data[k] = keep
+    assert P.SparseCholesky._quick_id(mats) == q0
+    A.data[k], A.data[k + 1] = A.data[k + 1], A.data[k]
+    assert P.SparseCholesky._quick_id(mats) != q0
