@@ -137,6 +137,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if world > 1 and "SCILMM_HOST_THREADS" not in os.environ and "OMP_NUM_THREADS" not in os.environ:
+        # the ranks of a node analyse the cohort at the same time: each gets its share of the CPUs this job may use
+        # (the library would otherwise size every rank's thread teams for all of them)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        os.environ["SCILMM_HOST_THREADS"] = str(max(1, _effective_cpus() // max(1, local_world)))
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % ndev)  # one rank per GPU under the driver; the modulo only matters in rehearsals
     dev = torch.device("cuda", local_rank % ndev)
