@@ -1116,7 +1116,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       for (int32_t d = 0; d < nT; ++d)
         for (int64_t e = S.tail_blk_ptr[d]; e < S.tail_blk_ptr[d + 1]; ++e) tail_src[(size_t)S.tail_blk[e]].push_back(d);
     }
-    int64_t dense_pairs_all = 0, dense_pairs_kept = 0;
+    std::vector<int32_t> tail_col_front;  // label - first tail column -> relative tail front
+    if (!tail_src.empty()) {
+      const int32_t c0t = S.sn_start[S.dense_first];
+      tail_col_front.resize((size_t)(S.n - c0t));
+      for (int32_t f = S.dense_first; f < S.nsuper; ++f)
+        for (int32_t c = S.sn_start[f]; c < S.sn_start[f + 1]; ++c) tail_col_front[(size_t)(c - c0t)] = f - S.dense_first;
+    }
+    int64_t dense_pairs_all = 0, dense_pairs_kept = 0, dense_tiles_all = 0, dense_tiles_kept = 0;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       int64_t total_e = 0, total_l = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
@@ -1128,6 +1135,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       // look_depth of them are "late", the others "early" -- implicit items, one per (pair of tiles, K segment)
       int32_t dj = -1, dcnt_e = 0, dcnt_l = 0;
       std::vector<std::pair<int32_t, int32_t>> segs_e, segs_l;  // descendant ranges of the level's dense items
+      std::vector<uint8_t> pair_on;                             // per tile pair of the dense target: does it get items
       const int64_t dunit = 1 + (NB + KC - 1) / KC;  // cost units of one tail descendant on one tile
       int32_t dfr = -1;  // the tail fronts lie on a chain: at most one of them per level
       if (D->dense_on)
@@ -1178,6 +1186,32 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           const int64_t act_e = build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
           dense_pairs_all += jj;
           dense_pairs_kept += act_e + act_l;
+          // rows of the target that NO active descendant reaches receive nothing but padding: their tile pairs get no
+          // items (below the dense region the fronts of one side branch do not reach the columns of the others, nor
+          // the part of the region sorted to its start)
+          pair_on.assign((size_t)npairs, 1);
+          if (!tail_src.empty() && jj > 0) {
+            const std::vector<int32_t>& src = tail_src[(size_t)jj];
+            const auto a_end = std::lower_bound(src.begin(), src.end(), jj);
+            const int32_t c0t = S.sn_start[S.dense_first], c0j = S.sn_start[fr];
+            for (int64_t pq = 0; pq < npairs; ++pq) {
+              const int64_t lo = (int64_t)c0j + 2 * TM * pq, hi = std::min<int64_t>(lo + 2 * TM, S.n);
+              const int32_t f_lo = tail_col_front[(size_t)(lo - c0t)], f_hi = tail_col_front[(size_t)(hi - 1 - c0t)];
+              bool need = f_lo <= jj;  // the target's own columns
+              for (int32_t f = std::max(f_lo, jj + 1); f <= f_hi && !need; ++f) {
+                const std::vector<int32_t>& sf = tail_src[(size_t)f];
+                auto x = src.begin();
+                auto y = sf.begin();
+                while (x != a_end && y != sf.end()) {
+                  if (*x < *y) ++x;
+                  else if (*y < *x) ++y;
+                  else { need = true; break; }
+                }
+              }
+              pair_on[(size_t)pq] = need ? 1 : 0;
+            }
+          }
+          for (uint8_t v : pair_on) { dense_tiles_all += 1; dense_tiles_kept += v; }
           total_e += ntl * dunit * act_e;
           total_l += ntl * dunit * act_l;
         }
@@ -1233,7 +1267,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         // a single dense item of a launch subtracts straight into the panel (the early and the late launch of a
         // level never overlap in time); two or more go through partial slabs; slab-mode compact items always do
         // (the implicit dense-tail items of the tile count like explicit ones: dte / dtl of them)
-        const int64_t dte = (dj >= 0 && S.tile_front[g] == dj) ? nde : 0, dtl = (dj >= 0 && S.tile_front[g] == dj) ? ndl : 0;
+        const bool dtile = dj >= 0 && S.tile_front[g] == dj && pair_on[(size_t)((g - S.tile_base[dj]) / 2)];
+        const int64_t dte = dtile ? nde : 0, dtl = dtile ? ndl : 0;
         const int64_t pe = (ne + dte) >= 2 ? ne : 0, pl = (nl + dtl) >= 2 ? nl : 0;
         const int64_t pde = (ne + dte) >= 2 ? dte : 0, pdl = (nl + dtl) >= 2 ? dtl : 0;
         if (ne == 1 && pe == 0) work_early[fe].slot = -1;
@@ -1289,6 +1324,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           for (size_t sg = 0; sg < segs.size(); ++sg) {
             const int32_t k0 = segs[sg].first, k1 = segs[sg].second;
             for (int32_t q = 0; q < ntl; q += 2) {
+              if (!pair_on[(size_t)(q / 2)]) continue;
               const int32_t nt2 = std::min<int32_t>(2, ntl - q);
               DenseWork wk{dj, q, nt2, k0, k1, base[(size_t)q] < 0 ? -1 : base[(size_t)q] + (int32_t)sg,
                            (nt2 == 2 && base[(size_t)q + 1] >= 0) ? base[(size_t)q + 1] + (int32_t)sg : -1, 0};
@@ -1364,8 +1400,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if ((st = upload(sym, D, dwork_l, &ddw)) != SCILMM_OK) return st;
       D->d_dwork_l = (DenseWork*)ddw;
       if (getenv("SCILMM_VERBOSE") && dense_pairs_all > 0)
-        fprintf(stderr, "[scilmm plan] dense tail: %lld of %lld (target, descendant) panel pairs carry true entries (the others are padding only and skipped)\n",
-                (long long)dense_pairs_kept, (long long)dense_pairs_all);
+        fprintf(stderr, "[scilmm plan] dense tail: %lld of %lld (target, descendant) panel pairs carry true entries, %lld of %lld target tile pairs are reached by a descendant (the others are padding only and skipped)\n",
+                (long long)dense_pairs_kept, (long long)dense_pairs_all, (long long)dense_tiles_kept, (long long)dense_tiles_all);
       if (getenv("SCILMM_VERBOSE"))
         fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d%s)\n",
                 S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,
