@@ -116,6 +116,49 @@ def cpu_baseline(A, r, sample_name):
             "factor_s": t_fact, "solve_s": t_solve, "flops_per_s": cinfo.flops / t_fact, "logdet": cpu.logdet()}
 
 
+def spawn_ranks(n):
+    """Launcher half of `python bench.py --gpus N`: N children of this interpreter with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set (127.0.0.1, a free port), the same command line; rank 0's stdout carries the JSON line.  The parent makes
+    no GPU call at all.  Returns the exit status: 0 only if every rank exited 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                # one rank failed: the others would wait in a collective until it times out
+                time.sleep(5.0)
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                worst = bad[0]
+                break
+    finally:
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                p.kill()
+    for p in procs:
+        if p.returncode not in (0, None) and worst == 0:
+            worst = p.returncode
+    if worst != 0:
+        sys.stderr.write("bench.py: a rank exited with status %s\n" % worst)
+    return 1 if worst != 0 else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +172,17 @@ def main():
                     help="32: BASELINE configs[4]'s arithmetic (fp32 MFMA fronts, fp64 sums) -- NOT the headline metric; "
                          "the line then says so in `dtype` and `metric`")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts the N ranks as
+        # fresh children BEFORE anything here touches the GPU (it never does) and leaves with their worst exit code.
+        raise SystemExit(spawn_ranks(args.gpus))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to print a line "
+                         "for a rank count that was not asked for" % (args.gpus, env_world))
 
     import torch
     import torch.distributed as dist
@@ -333,7 +387,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": warm_done,
             "steps_requested": args.steps, "warmup_requested": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if args.front_bits == 64 else "f64 sums / f32 MFMA products in the dense tail", "data": "synthetic",
             "config": {"workload": "simulated pedigree %s (n=%d after unrelated-drop, sparsity_factor %g), K=2 (A + I), "
                                    "r=%d fused right-hand sides" % (args.workload, n, WORKLOADS[args.workload][1], r),

@@ -57,6 +57,7 @@ def lib():
         L.sncpu_factorize.restype = C.c_int
         L.sncpu_factorize.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
         L.sncpu_solve.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp]
+        L.sncpu_lmul.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
         L.sncpu_factorize_range.restype = C.c_int
         L.sncpu_factorize_range.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
         _lib = L
@@ -280,6 +281,18 @@ class SupernodalCPU(object):
                           _p(self.Lx), self.n, Y.shape[1], _p(Y))
         return Y
 
+    def lmul(self, R):
+        """(L R)[argsort(P)] (simulate_vector, SparseCholesky.py:50-51): R is not permuted on the way in."""
+        a = self.a
+        R = np.asarray(R, dtype=np.float64)
+        Rf = np.asfortranarray(R.reshape(self.n, -1))
+        Y = np.empty_like(Rf)
+        lib().sncpu_lmul(self.ns, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_rows"]), _p(a["sn_loff"]), _p(self.Lx),
+                         self.n, Rf.shape[1], _p(Rf), _p(Y))
+        Z = np.empty((self.n, Rf.shape[1]))
+        Z[a["perm"]] = Y
+        return Z.reshape(R.shape)
+
     def solve(self, B):
         perm = self.a["perm"]
         B = np.asarray(B, dtype=np.float64)
@@ -288,6 +301,45 @@ class SupernodalCPU(object):
         X = np.empty((self.n, Y.shape[1]))
         X[perm] = Y
         return X.reshape(B.shape)
+
+
+class CPUPortFactor(object):
+    """Factor protocol (``factor(b)``, ``.L()``, ``.P()``, ``.logdet()`` + ``lmul``) on top of ``SupernodalCPU`` for a
+    given analysis: the CPU counterpart of the HIP factor at the sizes the simplicial C oracle cannot reach (100k
+    config: 1.7 TFLOP).  ``sym_arrays`` = ``Symbolic.arrays()`` (+ ``pat_colptr``) of the engine under test, so both
+    factor V[P][:,P] for the SAME P with the same supernode blocks -- through entirely different code (BLAS-3 on the
+    host vs. HIP kernels)."""
+
+    def __init__(self, sym_arrays, pat_colptr, V):
+        V = sp.csr_matrix(V)
+        self.n = n = V.shape[0]
+        self.cpu = SupernodalCPU(sym_arrays, n)
+        self._perm = np.asarray(sym_arrays["perm"])
+        p = self._perm
+        Lw = sp.tril(V[p][:, p]).tocsc()
+        Lw.sort_indices()
+        if not np.array_equal(Lw.indptr, pat_colptr):
+            raise ValueError("V does not have the analysed pattern")
+        self.cpu.assemble(Lw.data)  # pattern slots = CSC order of tril(V[P][:,P])
+        self.cpu.factorize()
+        self._L = None
+
+    def __call__(self, b):
+        return self.cpu.solve(b)
+
+    def L(self):
+        if self._L is None:
+            self._L = self.cpu.L_csc()
+        return self._L
+
+    def lmul(self, R):
+        return self.cpu.lmul(R)
+
+    def P(self):
+        return self._perm.astype(np.int64)
+
+    def logdet(self):
+        return self.cpu.logdet()
 
 
 def dominance(parents, A):

@@ -44,7 +44,8 @@ def evaluate(log_s2, mats, C, y, reml=True, sim_num=100, perm=None, factor_of=No
     if reml:
         nll += np.log(np.diag(G[0])).sum()
     R = np.random.randn(n, sim_num)
-    Z = (f.L() @ R)[pinv]
+    # (a factor that offers the fused product is asked for it: exporting L at the 100k config is 2 GB of CSC)
+    Z = f.lmul(R) if hasattr(f, "lmul") else (f.L() @ R)[pinv]
     U = f(Z)
     g = np.empty(len(s2))
     for k, Ak in enumerate(mats):

@@ -161,3 +161,27 @@ void sncpu_solve(int32_t ns, const int32_t* sn_start, const int64_t* sn_rowptr, 
   }
   free(W);
 }
+
+/* Y = L * R for column-major n x r blocks (leading dimension n), both in PERMUTED labels: the supernodal form of
+ * factor.L().dot(R) (reference scilmm/SparseCholesky.py:50).  The strict upper part of every diagonal block is zero
+ * after sncpu_factorize, so a panel multiplies as a plain m x w matrix. */
+void sncpu_lmul(int32_t ns, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows, const int64_t* sn_loff,
+                const double* Lx, int32_t n, int32_t r, const double* R, double* Y) {
+  char N = 'N';
+  double one = 1.0, zero = 0.0;
+  size_t wcap = 1 << 16;
+  double* W = (double*)malloc(sizeof(double) * wcap);
+  memset(Y, 0, sizeof(double) * (size_t)n * (size_t)r);
+  for (int32_t s = 0; s < ns; ++s) {
+    int32_t c0 = sn_start[s], w = sn_start[s + 1] - c0;
+    const int32_t* rs = sn_rows + sn_rowptr[s];
+    int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);
+    const double* P = Lx + sn_loff[s];
+    size_t need = (size_t)m * (size_t)r;
+    if (need > wcap) { wcap = need * 2; free(W); W = (double*)malloc(sizeof(double) * wcap); }
+    p_dgemm(&N, &N, &m, &r, &w, &one, (double*)P, &m, (double*)R + c0, &n, &zero, W, &m);
+    for (int32_t c = 0; c < r; ++c)
+      for (int32_t t = 0; t < m; ++t) Y[(size_t)c * n + rs[t]] += W[(size_t)c * m + t];
+  }
+  free(W);
+}

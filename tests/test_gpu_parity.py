@@ -449,3 +449,60 @@ def test_device_dominance_matches_oracle_and_reference_golden():
     assert _lib.dominance(sp.csr_matrix((0, 0)), np.zeros((0, 2), dtype=np.int32)).shape == (0, 0)
     with pytest.raises(_lib.ScilmmError):
         _lib.dominance(sp.identity(3, format="csr"), np.array([[-1, -1], [7, -1], [-1, -1]]))
+
+
+_CPU_PORT_100K = {}
+
+
+@pytest.mark.parametrize("env", [{}, {"SCILMM_TUNING": "1", "SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1"}],
+                         ids=["default-schedule", "dense+outside"])
+def test_100k_config_against_cpu_port(monkeypatch, env):
+    """BASELINE configs[1] at FULL size (100k individuals, sf 0.005; 1.7 TFLOP per factorization), value by value
+    against the BLAS-3 CPU port (oracle/supernodal_cpu.c) factoring the same V[P][:,P]: log-det and a 103-column
+    solve to 1e-10, L*R to 1e-10, and one REML evaluation through the drop-in `bolt_gradient_estimation` against
+    `reml_oracle.evaluate` driven by the CPU factor with the same np.random stream (nll 1e-10, gradient 1e-7).
+    Run with the default schedule of this size (explicit update items) and with the large-problem schedule the 300k /
+    1M configs use (k_dense_a + k_outside), forced here."""
+    import importlib
+    from oracle import oracle as O
+    from oracle import reml_oracle as RO
+    from scilmm_amd.harness.pedigree import make_problem
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P = importlib.import_module("scilmm_amd.SparseCholesky")
+    mats, C, y = make_problem(100000, 0.005, seed=0)
+    A = mats[0]
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    y = y / y.std()
+    chol = P.SparseCholesky()
+    sym = chol.engine_for([A, I])
+    s2 = np.array([0.4, 0.6])
+    V = (s2[0] * A + s2[1] * I).tocsr()
+    arrays, colptr = sym.arrays(), sym.get("pat_colptr")
+    ref = _CPU_PORT_100K
+    if not ref:
+        o = O.CPUPortFactor(arrays, colptr, V)
+        rng = np.random.default_rng(7)
+        ref["B"] = rng.standard_normal((n, 103))
+        ref["R"] = rng.standard_normal((n, 3))
+        ref["perm"] = o.P().copy()
+        ref["logdet"] = o.logdet()
+        ref["X"] = o(ref["B"])
+        ref["Z"] = o.lmul(ref["R"])
+        np.random.seed(11)
+        ref["eval"] = RO.evaluate(np.log(s2), [A, I], C, y, reml=True, sim_num=20,
+                                  factor_of=lambda Vx: O.CPUPortFactor(arrays, colptr, Vx))
+        del o
+    assert np.array_equal(sym.P(), ref["perm"])          # the analysis does not depend on the schedule switches
+    f = sym.factorize(s2)
+    assert abs(f.logdet() - ref["logdet"]) < TOL * abs(ref["logdet"])
+    assert rel_err(f(ref["B"]), ref["X"]) < TOL
+    assert rel_err(f.lmul(ref["R"]), ref["Z"]) < TOL
+    del f
+    np.random.seed(11)
+    nll, grad = P.bolt_gradient_estimation(np.log(s2), chol, [A, I], C, y, True, 20, False)
+    nll_o, grad_o = ref["eval"]
+    assert abs(nll - nll_o) < 1e-10 * abs(nll_o)
+    assert np.abs(grad - grad_o).max() < 1e-7 * np.abs(grad_o).max()
+    chol.release_factors()
