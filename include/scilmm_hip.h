@@ -76,7 +76,8 @@ typedef struct scilmm_info {
  * order (same fill). */
 int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const scilmm_options* opts, int32_t ngpus,
-                           scilmm_symbolic** out);
+                           scilmm_symbolic** out);  /* ngpus: must be >= 1; the analysis itself does not depend on it (the
+                                                       distribution is chosen by scilmm_dist_init) */
 int scilmm_symbolic_info(const scilmm_symbolic* sym, scilmm_info* info);
 /* Copy a named int32/int64 array of the analysis ("perm" replaces factor.P(), SparseCholesky.py:93).
  * Call with out == NULL to get the element count.  Names: perm, iperm, parent, colcount, sn_start, sn_parent,
@@ -114,22 +115,41 @@ int scilmm_refactorize_async(scilmm_factor* fac, const double* sigma2);
 int scilmm_factor_wait(scilmm_factor* fac, int32_t* bad_col);
 void scilmm_factor_free(scilmm_factor* fac);
 
-/* --- multi-GPU: one process per GPU.  The dense chain at the top of the block elimination tree
- * (the separator supernodes: >99 % of the flops of a pedigree factor) is distributed 1-D block-cyclically: a rank
- * computes every world-th chain panel and receives the others.  The library does not link a communication
- * library: it calls `fn` at ENQUEUE time, in the same order on every rank, and the callback issues the collective
- * on `comm_stream` (torch.distributed over RCCL in production, gloo in the CPU/1-GPU rehearsals):
- *   op 0 = broadcast from `root`;  buffer 0 = L, 1 = invD, 2 = logd (the arrays given to
- *   scilmm_factor_create_external);  offset / count in doubles.
+/* --- multi-GPU: one process per GPU, ONE cohort factored by all of them.  The fronts of the dense
+ * tail at the top of the block elimination tree (the separator supernodes: > 99 % of the flops and of the storage of a
+ * pedigree factor) are owned 1-D block-cyclically (tail front dense_first + j belongs to rank j % world); everything
+ * below (the "prelude") is replicated.  FAN-OUT with rank-local storage: a rank keeps the prelude, its OWN tail panels
+ * and a ring of a few panel slots through which the other ranks' panels pass -- a finished panel is broadcast by its
+ * owner, applied by every rank to those of its own targets that need it (the sources of a whole group of panels at a
+ * time, so the accumulators stay in registers over K = group x 128) and dropped.  Per rank nnz(L) / world + ring instead
+ * of nnz(L): this is what lets BASELINE configs[4] (3M individuals, ~1.3 TB of factor) fit 8 x 288 GB.  The triangular
+ * sweeps run with one small collective per tail block (forward: all-reduce of the block's accumulated contributions;
+ * backward: broadcast of the block's solution); L*R is summed by one all-reduce.  DESIGN.md section 7 has the numbers.
+ * The library links no communication library: it calls `fn` at ENQUEUE time, in the same order on every rank, and
+ * the callback issues the collective on `comm_stream` (torch.distributed over RCCL in production, gloo in rehearsals):
+ *   op 0 = broadcast from `root`, 1 = all-reduce (sum), 2 = all-reduce (min);
+ *   buffer 0 = L, 1 = invD, 2 = logd (the arrays given to scilmm_factor_create_external), 3 = the sweeps' work
+ *   buffer (scilmm_dist_set_work);  offset / count in doubles, offsets are RANK-LOCAL (the same panel lives at
+ *   different offsets on its owner and in a receiver's ring).
  * The engine orders its own streams against `comm_stream` with events (before the call: comm_stream waits for the
- * owner's kernels; after it: an event recorded on comm_stream releases the consumers).  Must be called before the
- * first numeric call on the handle.  The reference has no counterpart (single-process CHOLMOD). */
+ * producer's kernels; after it: an event recorded on comm_stream releases the consumers).  Must be called before the
+ * first numeric call on the handle.  A non-positive pivot is reported by EVERY rank (the status word is all-reduced).
+ * The reference has no counterpart (single-process CHOLMOD). */
 typedef int (*scilmm_comm_fn)(void* ctx, int32_t op, int32_t buffer, int64_t offset, int64_t count, int32_t root);
 int scilmm_dist_init(scilmm_symbolic* sym, int32_t rank, int32_t world, void* comm_stream, scilmm_comm_fn fn, void* ctx);
 /* Factor storage owned by the caller (so that the communication layer can address it, e.g. as torch tensors):
- * sizes in doubles incl. the slack the kernels over-read; then create the handle and use scilmm_refactorize. */
+ * sizes in doubles incl. the slack the kernels over-read -- of THIS rank's share once scilmm_dist_init has been called;
+ * then create the handle and use scilmm_refactorize. */
 int scilmm_factor_sizes(const scilmm_symbolic* sym, int64_t* L_doubles, int64_t* invD_doubles, int64_t* logd_doubles);
 int scilmm_factor_create_external(scilmm_symbolic* sym, double* L, double* invD, double* logd, scilmm_factor** out);
+/* Work buffer of the distributed sweeps (right-hand sides, solutions, the forward sweep's accumulator), caller-owned
+ * for the same reason: scilmm_dist_work_size doubles; required before the first solve / L*R when world > 1. */
+int scilmm_dist_work_size(const scilmm_symbolic* sym, int64_t* doubles);
+int scilmm_dist_set_work(scilmm_symbolic* sym, double* work);
+/* The distribution rule as data (tests cross-check the CPU rehearsal engine against it): owner[nsuper] (-1 = replicated),
+ * loff[nsuper + 1] rank-local panel offsets for `rank` of `world` (last entry: doubles of local panel storage),
+ * params = {first distributed front, group size, ring slots}.  Host only. */
+int scilmm_dist_layout(const scilmm_symbolic* sym, int32_t rank, int32_t world, int32_t* owner, int64_t* loff, int32_t* params);
 
 /* factor.logdet()  (SparseCholesky.py:40) */
 int scilmm_logdet(scilmm_factor* fac, double* out);

@@ -58,6 +58,12 @@ def lib():
         L.sncpu_factorize.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
         L.sncpu_solve.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp]
         L.sncpu_lmul.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
+        L.sncpu_update_from.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+        L.sncpu_finish.restype = C.c_int
+        L.sncpu_finish.argtypes = [i32, vp, vp, vp, vp]
+        L.sncpu_fwd_front.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32]
+        L.sncpu_bwd_front.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp]
+        L.sncpu_lmul_front.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
         L.sncpu_factorize_range.restype = C.c_int
         L.sncpu_factorize_range.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
         _lib = L
@@ -257,6 +263,33 @@ class SupernodalCPU(object):
 
     def logdet(self):
         return 2.0 * np.log(self.Lx[self.a["diag_dst"]]).sum()
+
+    # ---- one front at a time (oracle/dist_cpu.py); self.a["sn_loff"] may be a RANK-LOCAL offset table
+    def update_from(self, s, d_lo, d_hi):
+        a = self.a
+        lib().sncpu_update_from(s, d_lo, d_hi, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_rows"]), _p(a["sn_loff"]),
+                                _p(a["upd_ptr"]), _p(a["upd_src"]), _p(a["upd_p0"]), _p(a["upd_p1"]), self.n, _p(self.Lx))
+
+    def finish(self, s):
+        a = self.a
+        st = lib().sncpu_finish(s, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_loff"]), _p(self.Lx))
+        if st != 0:
+            raise NotPositiveDefinite(st - 1)
+
+    def fwd_front(self, s, Y, ACC, push):
+        a = self.a
+        lib().sncpu_fwd_front(s, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_rows"]), _p(a["sn_loff"]), _p(self.Lx), self.n,
+                              Y.shape[1], _p(Y), _p(ACC), int(push))
+
+    def bwd_front(self, s, Y):
+        a = self.a
+        lib().sncpu_bwd_front(s, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_rows"]), _p(a["sn_loff"]), _p(self.Lx), self.n,
+                              Y.shape[1], _p(Y))
+
+    def lmul_front(self, s, R, Y):
+        a = self.a
+        lib().sncpu_lmul_front(s, _p(a["sn_start"]), _p(a["sn_rowptr"]), _p(a["sn_rows"]), _p(a["sn_loff"]), _p(self.Lx), self.n,
+                               R.shape[1], _p(R), _p(Y))
 
     def L_csc(self):
         """The factor as scipy CSC (permuted labels), assembled from the panels."""

@@ -185,3 +185,121 @@ void sncpu_lmul(int32_t ns, const int32_t* sn_start, const int64_t* sn_rowptr, c
   }
   free(W);
 }
+
+/* ---- pieces of the factorization and of the sweeps, one front at a time: the units of work of the multi-rank rehearsal
+ * (oracle/dist_cpu.py), which runs the distribution rule of the HIP engine -- rank-local panel storage (sn_loff is the
+ * RANK's offset table: own panels, ring slots), batched fan-out updates, one collective per tail block in the sweeps. */
+
+/* target s receives the contributions of its descendants d with d_lo <= d < d_hi only */
+void sncpu_update_from(int32_t s, int32_t d_lo, int32_t d_hi, const int32_t* sn_start, const int64_t* sn_rowptr,
+                       const int32_t* sn_rows, const int64_t* sn_loff, const int64_t* upd_ptr, const int32_t* upd_src,
+                       const int32_t* upd_p0, const int32_t* upd_p1, int32_t n, double* Lx) {
+  int32_t* pos = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  size_t wcap = 1 << 16;
+  double* W = (double*)malloc(sizeof(double) * wcap);
+  char N = 'N', T = 'T';
+  double one = 1.0, zero = 0.0;
+  int32_t c0 = sn_start[s];
+  const int32_t* rs = sn_rows + sn_rowptr[s];
+  int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);
+  double* P = Lx + sn_loff[s];
+  for (int32_t t = 0; t < m; ++t) pos[rs[t]] = t;
+  for (int64_t e = upd_ptr[s]; e < upd_ptr[s + 1]; ++e) {
+    int32_t d = upd_src[e], p0 = upd_p0[e], p1 = upd_p1[e];
+    if (d < d_lo || d >= d_hi) continue;
+    const int32_t* rd = sn_rows + sn_rowptr[d];
+    int32_t md = (int32_t)(sn_rowptr[d + 1] - sn_rowptr[d]);
+    int32_t wd = sn_start[d + 1] - sn_start[d];
+    const double* Pd = Lx + sn_loff[d];
+    int32_t mm = md - p0, nn = p1 - p0;
+    size_t need = (size_t)mm * (size_t)nn;
+    if (need > wcap) { wcap = need * 2; free(W); W = (double*)malloc(sizeof(double) * wcap); }
+    p_dgemm(&N, &T, &mm, &nn, &wd, &one, (double*)Pd + p0, &md, (double*)Pd + p0, &md, &zero, W, &mm);
+    for (int32_t q = 0; q < nn; ++q) {
+      double* col = P + (size_t)(rd[p0 + q] - c0) * m;
+      const double* wq = W + (size_t)q * mm;
+      for (int32_t t = q; t < mm; ++t) col[pos[rd[p0 + t]]] -= wq[t];
+    }
+  }
+  free(pos); free(W);
+}
+
+/* potrf + trsm of the (fully updated) panel of front s; returns 0 or 1 + failing column */
+int sncpu_finish(int32_t s, const int32_t* sn_start, const int64_t* sn_rowptr, const int64_t* sn_loff, double* Lx) {
+  char N = 'N', T = 'T', Lo = 'L', R = 'R';
+  double one = 1.0;
+  int32_t c0 = sn_start[s], w = sn_start[s + 1] - c0;
+  int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);
+  double* P = Lx + sn_loff[s];
+  int info = 0;
+  p_dpotrf(&Lo, &w, P, &m, &info);
+  if (info != 0) return 1 + c0 + (info > 0 ? info - 1 : 0);
+  if (m > w) {
+    int32_t u = m - w;
+    p_dtrsm(&R, &Lo, &T, &N, &u, &w, &one, P, &m, P + w, &m);
+  }
+  for (int32_t j = 1; j < w; ++j)
+    for (int32_t i = 0; i < j; ++i) P[(size_t)j * m + i] = 0.0;
+  return 0;
+}
+
+/* forward step of front s on column-major n x r blocks, in two halves: push == 0: Y[c0:c0+w] <- L_ss^-1 Y[c0:c0+w] (needs
+ * the diagonal block only); push != 0: ACC[rows below] -= L_21 Y[c0:c0+w] (needs the whole panel: its owner's job).
+ * Y and ACC may be the same array (single-process sweep). */
+void sncpu_fwd_front(int32_t s, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows, const int64_t* sn_loff,
+                     const double* Lx, int32_t n, int32_t r, double* Y, double* ACC, int32_t push) {
+  char N = 'N', Lo = 'L', Le = 'L';
+  double one = 1.0, zero = 0.0;
+  int32_t c0 = sn_start[s], w = sn_start[s + 1] - c0;
+  const int32_t* rs = sn_rows + sn_rowptr[s];
+  int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);
+  const double* P = Lx + sn_loff[s];
+  if (!push) {  /* diagonal block only: needs the w x w block, which every rank has (replicated inverse in the HIP engine) */
+    p_dtrsm(&Le, &Lo, &N, &N, &w, &r, &one, (double*)P, &m, Y + c0, &n);
+    return;
+  }
+  int32_t u = m - w;
+  if (u > 0) {
+    double* W = (double*)malloc(sizeof(double) * (size_t)u * (size_t)r);
+    p_dgemm(&N, &N, &u, &r, &w, &one, (double*)P + w, &m, Y + c0, &n, &zero, W, &u);
+    for (int32_t c = 0; c < r; ++c)
+      for (int32_t t = 0; t < u; ++t) ACC[(size_t)c * n + rs[w + t]] -= W[(size_t)c * u + t];
+    free(W);
+  }
+}
+
+/* backward step of front s: Y[c0:c0+w] <- L_ss^-T (Y[c0:c0+w] - L_21^T Y[rows below]) */
+void sncpu_bwd_front(int32_t s, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows, const int64_t* sn_loff,
+                     const double* Lx, int32_t n, int32_t r, double* Y) {
+  char N = 'N', T = 'T', Lo = 'L', Le = 'L';
+  double one = 1.0, mone = -1.0;
+  int32_t c0 = sn_start[s], w = sn_start[s + 1] - c0;
+  const int32_t* rs = sn_rows + sn_rowptr[s];
+  int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);
+  const double* P = Lx + sn_loff[s];
+  int32_t u = m - w;
+  if (u > 0) {
+    double* W = (double*)malloc(sizeof(double) * (size_t)u * (size_t)r);
+    for (int32_t c = 0; c < r; ++c)
+      for (int32_t t = 0; t < u; ++t) W[(size_t)c * u + t] = Y[(size_t)c * n + rs[w + t]];
+    p_dgemm(&T, &N, &w, &r, &u, &mone, (double*)P + w, &m, W, &u, &one, Y + c0, &n);
+    free(W);
+  }
+  p_dtrsm(&Le, &Lo, &T, &N, &w, &r, &one, (double*)P, &m, Y + c0, &n);
+}
+
+/* Y += L[:, columns of s] * R[c0:c0+w]  (one front's share of L * R) */
+void sncpu_lmul_front(int32_t s, const int32_t* sn_start, const int64_t* sn_rowptr, const int32_t* sn_rows, const int64_t* sn_loff,
+                      const double* Lx, int32_t n, int32_t r, const double* R, double* Y) {
+  char N = 'N';
+  double one = 1.0, zero = 0.0;
+  int32_t c0 = sn_start[s], w = sn_start[s + 1] - c0;
+  const int32_t* rs = sn_rows + sn_rowptr[s];
+  int32_t m = (int32_t)(sn_rowptr[s + 1] - sn_rowptr[s]);
+  const double* P = Lx + sn_loff[s];
+  double* W = (double*)malloc(sizeof(double) * (size_t)m * (size_t)r);
+  p_dgemm(&N, &N, &m, &r, &w, &one, (double*)P, &m, (double*)R + c0, &n, &zero, W, &m);
+  for (int32_t c = 0; c < r; ++c)
+    for (int32_t t = 0; t < m; ++t) Y[(size_t)c * n + rs[t]] += W[(size_t)c * m + t];
+  free(W);
+}

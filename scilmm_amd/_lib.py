@@ -65,7 +65,7 @@ SYMBOLS = [
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free",
     "scilmm_order", "scilmm_fill_count",
-    "scilmm_dist_init", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments", "scilmm_set_front_precision",
+    "scilmm_dist_init", "scilmm_dist_work_size", "scilmm_dist_set_work", "scilmm_dist_layout", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments", "scilmm_set_front_precision",
     "scilmm_mm_read", "scilmm_mm_export", "scilmm_mm_error", "scilmm_mm_free",
     "scilmm_dominance", "scilmm_dominance_dev", "scilmm_dominance_error",
 ]
@@ -134,6 +134,9 @@ def lib():
     L.scilmm_he_moments.argtypes = [vp, i32, i32, P(dbl), P(dbl)]
     L.scilmm_dist_init.argtypes = [vp, i32, i32, vp, vp, vp]
     L.scilmm_factor_sizes.argtypes = [vp, P(i64), P(i64), P(i64)]
+    L.scilmm_dist_work_size.argtypes = [vp, P(i64)]
+    L.scilmm_dist_set_work.argtypes = [vp, vp]
+    L.scilmm_dist_layout.argtypes = [vp, i32, i32, vp, vp, vp]
     L.scilmm_factor_create_external.argtypes = [vp, vp, vp, vp, P(vp)]
     L.scilmm_dominance.argtypes = [i32, vp, vp, vp, vp, vp]
     L.scilmm_dominance_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp]

@@ -15,8 +15,7 @@ extern "C" {
 int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, const int32_t* const* indices,
                            const int32_t* perm_in, const scilmm_options* opts, int32_t ngpus, scilmm_symbolic** out) {
   scilmm::use_host_threads();
-  (void)ngpus;
-  if (!out || n < 0 || K <= 0 || !indptr || !indices) return SCILMM_ERR_ARG;
+  if (!out || n < 0 || K <= 0 || !indptr || !indices || ngpus < 1) return SCILMM_ERR_ARG;
   scilmm::SymbolicOptions o;
   if (opts) {
     o.ordering = opts->ordering;

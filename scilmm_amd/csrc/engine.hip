@@ -34,7 +34,8 @@ struct Dev {
   int32_t* d_level_tiles = nullptr;
   int32_t* d_level_fronts = nullptr;
   int32_t* d_level_pairs = nullptr;
-  int32_t* d_all_tiles = nullptr;  // identity list of tiles that carry rows (for L*R)
+  int32_t* d_all_fronts = nullptr;  // multi-GPU: Symbolic::level_fronts unfiltered (the forward sweep solves every
+                                    // tail block on every rank: the inverse diagonal blocks are replicated)
   std::vector<double*> vals;       // per matrix: pattern-order values or diagonal values
   std::vector<uint8_t> have_vals;
   double* W = nullptr;             // n x RPMAX workspaces (permuted right-hand sides)
@@ -55,21 +56,13 @@ struct Dev {
   UpdWork* d_work_early = nullptr; // EARLY items (older descendants): side stream, overlaps the previous level
   std::vector<int64_t> early_ptr;  // [nlevels+1]
   int64_t max_slots = 0;           // partial slabs per scratch half (scratch is double-buffered by level parity)
-  // compact path (k_update_compact): sparse combos multiplied in their own coordinates, scattered into slabs
-  ComboDesc* d_ccombos = nullptr;
-  UpdWork* d_cwork = nullptr;      // late
-  UpdWork* d_cwork_early = nullptr;
-  std::vector<int64_t> cwork_ptr, cearly_ptr;  // [nlevels+1]
-  int64_t n_compact_combos = 0;
-  int compact_mode = 0;            // 0 off; 1 = (tile, half) items subtract into the panel after the dense kernel;
-                                   // 2 = items write private partial slabs and run BESIDE the dense kernel (folded by k_reduce)
   hipStream_t side = nullptr;
   hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
   hipStream_t side3 = nullptr;     // optional third one (SCILMM_SIDE_STREAMS=3)
-  hipStream_t cside[2] = {nullptr, nullptr};  // compact path: its few long items run beside the next levels' dense updates
   int nside = 2;
   std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
   hipEvent_t ev_asm = nullptr;
+  hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // main <-> comm stream hand-offs (multi-GPU)
   int32_t* d_tile_pslot = nullptr;   // late partial slabs of a tile (main stream)
   int32_t* d_tile_pnseg = nullptr;
   int32_t* d_tile_pslot_e = nullptr; // early partial slabs of a tile (side stream)
@@ -89,28 +82,35 @@ struct Dev {
     int32_t* wd = nullptr;
     std::vector<int64_t> level_ptr;    // [nlevels+1] over unique target cells
     std::vector<int64_t> level_short;  // [nlevels] short groups (listed first) per level
-  } cellset[3];  // 0 = early (side streams), 1 = late (main stream; split levels: diagonal tile only), 2 = late, rest stream
+  } cellset[3];  // 0 = early (side streams), 1 = late (main stream); 2 unused (kept for the device cell plan's key layout)
   int64_t n_dense_combos = 0, n_sparse_combos = 0, n_cells = 0;
   std::vector<int64_t> red_ptr;    // [nlevels+1]
   bool profiling = false;
   int ablate = 0;
-  // chain levels in split mode: only [late update of the diagonal tile, potrf, trsm of the rows the next diagonal
-  // block needs] stay on the main stream; the other tiles' late update and trsm run one step behind on `rest`
-  hipStream_t rest = nullptr;
-  std::vector<uint8_t> split_lv;        // [nlevels]
-  std::vector<int64_t> work_split;      // [nlevels] late items of the diagonal tile (they come first in the level)
-  std::vector<int64_t> red_split;       // [nlevels] late reduce tiles of the diagonal tile
-  int32_t* d_trsm_split = nullptr;      // per split level: critical tiles, then the rest
-  std::vector<int64_t> trsm_sptr;       // [2 nlevels + 1]
-  std::vector<hipEvent_t> chain_ev;     // 3 per level: potrf done, rest-stream late update done, critical trsm done
-  // multi-GPU: the dense chain at the top of the block etree (levels >= dist_l0, one front each) is owned 1-D
-  // block-cyclically; a rank plans / computes only its own chain panels and receives the others by broadcast
+  // multi-GPU: the fronts of the dense tail (>= dist_first) are owned 1-D block-cyclically.  A rank STORES the prelude
+  // (replicated), its own tail panels and a ring of dist_G slots through which the other ranks' panels pass (fan-out:
+  // a received panel is applied to every own target that needs it and then dropped) -- see DistLayout.
   int32_t rank = 0, world = 1;
-  int32_t dist_l0 = 0;                  // first level of the distributed chain (nlevels when world == 1)
+  int32_t dist_first = 0;               // first distributed front (nsuper: nothing is distributed)
+  int32_t dist_Wg = 8, dist_G = 32;     // source-group size of the batched updates; ring slots
+  std::vector<int64_t> loff;            // [nsuper+1] rank-local panel offsets (== Symbolic::sn_loff when world == 1)
+  int64_t nL_local = 0;                 // doubles of rank-local panel storage (prelude + own tail + ring)
   std::vector<uint8_t> keep_front;      // [nsuper] this rank computes the panel of front s
-  std::vector<uint8_t> own_level;       // [nlevels] this rank runs the kernels of level l
+  std::vector<int32_t> tail_of_level;   // [nlevels] the distributed front of level l, or -1
+  // level lists without the tail fronts of other ranks (== the Symbolic's when world == 1)
+  std::vector<int32_t> lv_ptr, lv_fronts, lv_tiles, lv_pairs;  // lv_ptr: [nlevels+1] into lv_fronts
+  std::vector<int64_t> lv_tile_ptr, lv_tile_mid, lv_pair_ptr;  // lv_tile_mid[l]: first tile of the level's own distributed panel
+  int32_t* d_lmul_tiles = nullptr;      // tiles this rank multiplies in L*R (own tail; the prelude on rank 0 only)
+  int64_t n_lmul_tiles = 0;
+  DenseWork* d_dwork_b = nullptr;       // batch items of the distributed tail
+  std::vector<int64_t> dbatch_ptr;      // [ngroups+1]
+  std::vector<hipEvent_t> batch_ev;     // [ngroups] batch g applied to all own targets
+  std::vector<int32_t> last_own_level;  // [ngroups] level of this rank's last own tail front in group g, or -1
+  hipStream_t bstream = nullptr;        // the batches' stream
   hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
-  std::vector<hipEvent_t> done_ev;      // per level: kernels of an owned chain level finished (main stream)
+  std::vector<hipEvent_t> done_ev;      // per level with a distributed front: this rank's kernels of the level finished
+  double* ACC = nullptr;                // forward sweep: contributions of this rank's own tail panels, n x RPMAX (dist)
+  bool work_external = false;           // W / X / ACC belong to the caller (scilmm_dist_set_work)
   // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
   // prelude -> tail contributions in descendant coordinates (k_outside; fp64 atomics): one launch between the last
   // prelude level and the first tail level
@@ -125,15 +125,11 @@ struct Dev {
   hipEvent_t out_ev = nullptr;
   bool dense_on = false;
   int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
-  int dense_mf = 16;                    // matrix instruction of k_dense: 16 = v_mfma_f64_16x16x4, 4 = v_mfma_f64_4x4x4
-  int dense_glds = 2;                   // 16x16x4 form: 2 = A fragments from registers, B 64 deep by LDS-DMA (k_dense_a),
-                                        // 1 = both operands by LDS-DMA (k_dense_g), 0 = staged through registers (k_dense)
-  double* d_zeros = nullptr;            // 2 KiB of zeros: source of the k-rows past a descendant's end (k_dense_g)
+  double* d_zeros = nullptr;            // 2 KiB of zeros: source of the B k-rows past a descendant's end (k_dense_a)
   DenseWork* d_dwork_e = nullptr;
   DenseWork* d_dwork_l = nullptr;
   std::vector<int64_t> dwork_e_ptr, dwork_l_ptr;  // [nlevels+1]
   int look_depth = 2;      // "late" = descendants at most this many levels below the target; older ones are "early"
-  int update_variant = 2;  // 2 = k_update2 (staging interleaved with the MFMA k-steps), 1 = k_update
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   // dense-chain sweeps (k_chain): the last chain_T levels are single fronts whose mutual update pairs are contiguous
   int32_t chain_T = 0, chain_l0 = 0;
@@ -213,8 +209,8 @@ void dev_free(void* p) {
   for (void* a : D->allocs) (void)hipFree(a);
   for (double* v : D->vals)
     if (v) (void)hipFree(v);
-  if (D->W) (void)hipFree(D->W);
-  if (D->X) (void)hipFree(D->X);
+  if (D->W && !D->work_external) (void)hipFree(D->W);
+  if (D->X && !D->work_external) (void)hipFree(D->X);
   if (D->IO) (void)hipFree(D->IO);
   if (D->partial) (void)hipFree(D->partial);
   if (D->d_out) (void)hipFree(D->d_out);
@@ -225,20 +221,20 @@ void dev_free(void* p) {
   for (auto& e : D->lev_ev)
     if (e) (void)hipEventDestroy(e);
   if (D->ev_asm) (void)hipEventDestroy(D->ev_asm);
+  if (D->ev_x0) (void)hipEventDestroy(D->ev_x0);
+  if (D->ev_x1) (void)hipEventDestroy(D->ev_x1);
   if (D->side) (void)hipStreamDestroy(D->side);
   if (D->side2) (void)hipStreamDestroy(D->side2);
   if (D->side3) (void)hipStreamDestroy(D->side3);
-  for (auto& cs : D->cside)
-    if (cs) (void)hipStreamDestroy(cs);
-  if (D->rest) (void)hipStreamDestroy(D->rest);
   if (D->outside_st) (void)hipStreamDestroy(D->outside_st);
   if (D->out_ev) (void)hipEventDestroy(D->out_ev);
   if (D->h_chain_err) (void)hipHostFree(D->h_chain_err);
-  for (auto& e : D->chain_ev)
-    if (e) (void)hipEventDestroy(e);
   if (D->stream) (void)hipStreamDestroy(D->stream);
   for (auto& e : D->done_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : D->batch_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (D->bstream) (void)hipStreamDestroy(D->bstream);
   delete D;
 }
 
@@ -433,6 +429,47 @@ int build_cells_device(scilmm_symbolic* sym, Dev* D, const std::vector<const std
   return SCILMM_OK;
 }
 
+// Rank-local storage of a distributed factor (world > 1).  Tail front dense_first + jj belongs to rank jj % world.
+//   [ prelude panels, as in the Symbolic | own tail panels, packed | ring: G slots of the largest tail panel ]
+// A panel of another rank lives in slot jj % G from its broadcast until every own target has consumed it: the batch of
+// its source group g = jj / Wg (applied when the group is complete) and the late updates of the own targets of groups
+// g and g + 1 -- so a slot is free again well before panel jj + G arrives (G = 4 Wg; the level loop still orders the
+// re-use with events).  Per rank: nnz(L_tail) / world + G panels instead of the whole factor.
+struct DistLayout {
+  int32_t first = 0, Wg = 8, G = 32;
+  std::vector<int64_t> loff;
+  int64_t nL = 0, ring_base = 0, slot = 0;
+};
+void dist_layout(const Symbolic& S, int32_t rank, int32_t world, DistLayout* o) {
+  o->loff.assign(S.sn_loff.begin(), S.sn_loff.end());
+  o->nL = std::max<int64_t>(S.nnzL_stored, 1);
+  o->first = S.nsuper;
+  if (world <= 1 || S.dense_first >= S.nsuper) return;
+  o->first = S.dense_first;
+  int32_t wg = world;
+  while (wg < 8) wg += world;
+  if (const char* e = tune_env("SCILMM_DIST_GROUP")) wg = std::max(world, atoi(e) / world * world);
+  o->Wg = wg;
+  o->G = 4 * wg;
+  const int32_t nT = S.nsuper - o->first;
+  int64_t at = S.sn_loff[o->first];
+  for (int32_t jj = 0; jj < nT; ++jj) {
+    const int32_t f = o->first + jj;
+    const int64_t sz = S.sn_loff[f + 1] - S.sn_loff[f];
+    o->slot = std::max(o->slot, (sz + 1) & ~(int64_t)1);
+    if (jj % world == rank) {
+      o->loff[f] = at;
+      at += (sz + 1) & ~(int64_t)1;
+    }
+  }
+  o->ring_base = at;
+  const int32_t nslots = std::min(o->G, nT);
+  for (int32_t jj = 0; jj < nT; ++jj)
+    if (jj % world != rank) o->loff[o->first + jj] = o->ring_base + (int64_t)(jj % o->G) * o->slot;
+  o->nL = o->ring_base + (int64_t)nslots * o->slot;
+  o->loff[S.nsuper] = o->nL;
+}
+
 int ensure_device(scilmm_symbolic* sym, Dev** out) {
   if (sym->device) {
     *out = (Dev*)sym->device;
@@ -491,8 +528,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     } else {
       HIPCHK(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, lo));
       HIPCHK(hipStreamCreateWithPriority(&D->side2, hipStreamNonBlocking, lo));
-      HIPCHK(hipStreamCreateWithPriority(&D->cside[0], hipStreamNonBlocking, lo));
-      HIPCHK(hipStreamCreateWithPriority(&D->cside[1], hipStreamNonBlocking, lo));
       const char* ens3 = tune_env("SCILMM_SIDE_STREAMS");
       if (ens3 && atoi(ens3) == 3) {
         HIPCHK(hipStreamCreateWithPriority(&D->side3, hipStreamNonBlocking, lo));
@@ -502,14 +537,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       }
     }
   }
-  {
-    int lo2 = 0, hi2 = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo2, &hi2));
-    HIPCHK(hipStreamCreateWithPriority(&D->rest, hipStreamNonBlocking, hi2));
-  }
-  D->chain_ev.assign((size_t)3 * std::max(sym->S->nlevels, 1), nullptr);
-  for (auto& e : D->chain_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&D->ev_asm, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&D->ev_x0, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&D->ev_x1, hipEventDisableTiming));
   D->lev_ev.assign((size_t)2 * std::max(S.nlevels, 1), nullptr);
   for (auto& e : D->lev_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : D->ev) HIPCHK(hipEventCreate(&e));
@@ -524,41 +554,80 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   const char* ab = getenv("SCILMM_ABLATE");  // timing ablations (WRONG numbers): diagnostic builds only
   D->ablate = ab ? atoi(ab) : 0;
 #endif
-  const char* uv = tune_env("SCILMM_UPDATE_VARIANT");
-  if (uv) D->update_variant = atoi(uv);
-  // ---- multi-GPU ownership: the trailing run of single-front levels is the distributed chain
+  // ---- multi-GPU ownership and rank-local storage
   D->rank = sym->rank;
   D->world = std::max<int32_t>(1, sym->world);
   D->comm = (hipStream_t)sym->comm_stream;
-  D->dist_l0 = S.nlevels;
   D->keep_front.assign((size_t)std::max(S.nsuper, 1), 1);
-  D->own_level.assign((size_t)std::max(S.nlevels, 1), 1);
-  if (D->world > 1) {
-    int32_t l0 = S.nlevels;
-    while (l0 > 0 && S.level_ptr[l0] - S.level_ptr[l0 - 1] == 1) --l0;
-    D->dist_l0 = l0;
-    for (int32_t l = l0; l < S.nlevels; ++l) {
-      const bool mine = ((l - l0) % D->world) == D->rank;
-      D->own_level[l] = mine ? 1 : 0;
-      D->keep_front[S.level_fronts[S.level_ptr[l]]] = mine ? 1 : 0;
+  D->tail_of_level.assign((size_t)std::max(S.nlevels, 1), -1);
+  {
+    DistLayout lay;
+    dist_layout(S, D->rank, D->world, &lay);
+    D->dist_first = lay.first;
+    D->dist_Wg = lay.Wg;
+    D->dist_G = lay.G;
+    D->loff.swap(lay.loff);
+    D->nL_local = lay.nL;
+  }
+  if (D->world > 1 && D->dist_first < S.nsuper) {
+    const int32_t nT = S.nsuper - D->dist_first, ngroups = (nT + D->dist_Wg - 1) / D->dist_Wg;
+    for (int32_t f = D->dist_first; f < S.nsuper; ++f) {
+      D->keep_front[f] = ((f - D->dist_first) % D->world) == D->rank ? 1 : 0;
+      if (D->tail_of_level[S.sn_level[f]] >= 0) {
+        sym->err = "multi-GPU: two fronts of the dense tail share a level (the tail is expected to be a chain)";
+        return SCILMM_ERR_ARG;
+      }
+      D->tail_of_level[S.sn_level[f]] = f;
     }
     D->done_ev.assign((size_t)std::max(S.nlevels, 1), nullptr);
-    for (int32_t l = l0; l < S.nlevels; ++l) HIPCHK(hipEventCreateWithFlags(&D->done_ev[l], hipEventDisableTiming));
+    for (int32_t l = 0; l < S.nlevels; ++l)
+      if (D->tail_of_level[l] >= 0) HIPCHK(hipEventCreateWithFlags(&D->done_ev[l], hipEventDisableTiming));
+    D->batch_ev.assign((size_t)ngroups, nullptr);
+    for (auto& e : D->batch_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    D->last_own_level.assign((size_t)ngroups, -1);
+    for (int32_t f = D->dist_first; f < S.nsuper; ++f)
+      if (D->keep_front[f]) D->last_own_level[(size_t)((f - D->dist_first) / D->dist_Wg)] = S.sn_level[f];
+    int lo3 = 0, hi3 = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo3, &hi3));
+    HIPCHK(hipStreamCreateWithPriority(&D->bstream, hipStreamNonBlocking, lo3));
     if (pverb)
-      fprintf(stderr, "[scilmm plan] rank %d of %d: distributed chain = levels %d..%d (%d panels, every %d-th one mine)\n", D->rank,
-              D->world, l0, S.nlevels - 1, S.nlevels - l0, D->world);
+      fprintf(stderr, "[scilmm plan] rank %d of %d: %d tail panels distributed (every %d-th one mine), groups of %d, ring of %d slots; "
+              "local panel storage %.2f GB of %.2f GB\n", D->rank, D->world, nT, D->world, D->dist_Wg, D->dist_G,
+              8e-9 * (double)D->nL_local, 8e-9 * (double)S.nnzL_stored);
   }
+  // level lists of this rank: everything except the tail fronts of other ranks
+  {
+    D->lv_ptr.assign(1, 0);
+    D->lv_tile_ptr.assign(1, 0);
+    D->lv_pair_ptr.assign(1, 0);
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+      for (int32_t q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q)
+        if (D->keep_front[S.level_fronts[q]]) D->lv_fronts.push_back(S.level_fronts[q]);
+      // (tiles of an own distributed panel last: the forward sweep pushes them into a different accumulator)
+      for (int64_t q = S.level_tile_ptr[l]; q < S.level_tile_ptr[l + 1]; ++q)
+        if (S.tile_front[S.level_tiles[q]] < D->dist_first) D->lv_tiles.push_back(S.level_tiles[q]);
+      D->lv_tile_mid.push_back((int64_t)D->lv_tiles.size());
+      for (int64_t q = S.level_tile_ptr[l]; q < S.level_tile_ptr[l + 1]; ++q)
+        if (S.tile_front[S.level_tiles[q]] >= D->dist_first && D->keep_front[S.tile_front[S.level_tiles[q]]]) D->lv_tiles.push_back(S.level_tiles[q]);
+      // backward pushes (target in level l -> descendant d): this rank needs the panel of d
+      for (int64_t q = S.level_pair_ptr[l]; q < S.level_pair_ptr[l + 1]; ++q)
+        if (D->keep_front[S.upd_src[S.level_pairs[q]]]) D->lv_pairs.push_back(S.level_pairs[q]);
+      D->lv_ptr.push_back((int32_t)D->lv_fronts.size());
+      D->lv_tile_ptr.push_back((int64_t)D->lv_tiles.size());
+      D->lv_pair_ptr.push_back((int64_t)D->lv_pairs.size());
+    }
+  }
+  const std::vector<int64_t>& LOFF = D->loff;
   {
     // k_dense pays from a few hundred tail panels on (300k pedigree: 450 panels, factorization 1.97 -> 1.90 s; 1M: 1330
     // panels); on a short tail (100k: 135 panels) its one-workgroup-per-CU items balance worse than the explicit
     // path's (66 -> 72 ms), so it is switched on by the width of the tail.  SCILMM_DENSE=1 / 0 forces it.
     const char* edn = tune_env("SCILMM_DENSE");
     const int32_t tail_w = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
-    D->dense_on = S.dense_first < S.nsuper && (edn ? edn[0] != '0' : tail_w >= 32768);
-    const char* emf = tune_env("SCILMM_DENSE_MF");
-    if (emf) D->dense_mf = atoi(emf) == 4 ? 4 : 16;
-    const char* egl = tune_env("SCILMM_DENSE_GLDS");
-    if (egl) D->dense_glds = egl[0] == '0' ? 0 : egl[0] == '1' ? 1 : 2;
+    // (k_dense_a has no scalar form: with SCILMM_NO_MFMA=1 the tail goes through the explicit items of k_update2<false>)
+    D->dense_on = S.dense_first < S.nsuper && D->use_mfma && (edn ? edn[0] != '0' : tail_w >= 32768);
+    // a distributed tail is always updated by the implicit items (the batches have no explicit-combo form)
+    if (D->world > 1 && D->dist_first < S.nsuper) D->dense_on = true;
     if (D->dense_on && !D->d_zeros) {
       HIPCHK(hipMalloc((void**)&D->d_zeros, 2048));
       HIPCHK(hipMemset(D->d_zeros, 0, 2048));
@@ -638,7 +707,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   UP(sn_start, sn_start)
   UP(sn_rowptr, sn_rowptr)
   UP(sn_rows, sn_rows)
-  UP(sn_loff, sn_loff)
+  if ((st = upload(sym, D, D->loff, &D->v.sn_loff)) != SCILMM_OK) return st;
   UP(inv_off, inv_off)
   UP(upd_src, upd_src)
   UP(upd_p0, upd_p0)
@@ -650,19 +719,52 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   D->v.combo_pair = nullptr;
   D->v.combo_ta = nullptr;
   D->v.combo_tb = nullptr;
-  UP(asm_dst, asm_dst)
-  UP(diag_dst, diag_dst)
+  if (D->world > 1 && D->dist_first < S.nsuper) {
+    // value-assembly maps in rank-local offsets; entries of other ranks' tail panels are dropped (-1)
+    std::vector<int64_t> ad(S.asm_dst.size()), dd(S.diag_dst.size());
+    const int nth = std::max(1, std::min(16, scilmm::host_threads()));
+    std::vector<std::thread> pool;
+    auto part = [&](int q) {
+      for (int32_t f = q; f < S.nsuper; f += nth) {
+        const bool keep = D->keep_front[f] != 0;
+        const int64_t delta = LOFF[f] - S.sn_loff[f];
+        for (int32_t j = S.sn_start[f]; j < S.sn_start[f + 1]; ++j) {
+          dd[(size_t)j] = keep ? S.diag_dst[(size_t)j] + delta : -1;
+          for (int64_t e = S.pat_colptr[j]; e < S.pat_colptr[j + 1]; ++e) ad[(size_t)e] = keep ? S.asm_dst[(size_t)e] + delta : -1;
+        }
+      }
+    };
+    for (int q = 1; q < nth; ++q) pool.emplace_back(part, q);
+    part(0);
+    for (auto& th : pool) th.join();
+    if ((st = upload(sym, D, ad, &D->v.asm_dst)) != SCILMM_OK) return st;
+    if ((st = upload(sym, D, dd, &D->v.diag_dst)) != SCILMM_OK) return st;
+  } else {
+    UP(asm_dst, asm_dst)
+    UP(diag_dst, diag_dst)
+  }
   UP(pat_colptr, pat_colptr)
   UP(pat_row, pat_row)
   UP(perm, perm)
 #undef UP
   const int32_t* tmp;
-  if ((st = upload(sym, D, S.level_tiles, &tmp)) != SCILMM_OK) return st;
+  if ((st = upload(sym, D, D->lv_tiles, &tmp)) != SCILMM_OK) return st;
   D->d_level_tiles = (int32_t*)tmp;
-  if ((st = upload(sym, D, S.level_fronts, &tmp)) != SCILMM_OK) return st;
+  if ((st = upload(sym, D, D->lv_fronts, &tmp)) != SCILMM_OK) return st;
   D->d_level_fronts = (int32_t*)tmp;
-  if ((st = upload(sym, D, S.level_pairs, &tmp)) != SCILMM_OK) return st;
+  if ((st = upload(sym, D, D->lv_pairs, &tmp)) != SCILMM_OK) return st;
   D->d_level_pairs = (int32_t*)tmp;
+  if (D->world > 1) {
+    // L*R: every panel is multiplied by exactly one rank (own tail panels; the replicated prelude by rank 0), then summed
+    std::vector<int32_t> lt;
+    for (int32_t g : D->lv_tiles)
+      if (S.tile_front[g] >= D->dist_first || D->rank == 0) lt.push_back(g);
+    D->n_lmul_tiles = (int64_t)lt.size();
+    if ((st = upload(sym, D, lt, &tmp)) != SCILMM_OK) return st;
+    D->d_lmul_tiles = (int32_t*)tmp;
+    if ((st = upload(sym, D, S.level_fronts, &tmp)) != SCILMM_OK) return st;
+    D->d_all_fronts = (int32_t*)tmp;
+  }
   D->vals.assign(S.K, nullptr);
   D->have_vals.assign(S.K, 0);
   HIPCHK(hipMalloc((void**)&D->d_out, sizeof(double) * RPMAX));
@@ -699,60 +801,24 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     {
       const char* eld = tune_env("SCILMM_LOOK_DEPTH");
       D->look_depth = eld ? std::max(1, atoi(eld)) : 2;  // measured at 100k: depth 1 81.4 ms, 2 77.6 ms, 3 78.4 ms
-      // multi-GPU: a rank owns every world-th chain panel; everything older than its previous own panel is "early"
-      // work that needs nothing still in flight, the last `world` source panels are applied as they arrive
-      if (D->world > 1 && !eld) D->look_depth = std::max(2, D->world);
     }
     const int32_t depth = D->look_depth;
-    D->split_lv.assign(std::max(S.nlevels, 1), 0);
-    std::vector<int32_t> crit_t0(std::max(S.nlevels, 1), 0), crit_t1(std::max(S.nlevels, 1), -1);
-    {
-      // Opt-in (SCILMM_SPLIT_CHAIN=1): measured at the 100k pedigree it moves factorize from 74.7 to 73.8 ms only --
-      // the rest stream's [trsm of level l-1, late update of level l] is as long as the main stream's chain, and
-      // under the saturating early updates both run ~1.6x slower than isolated.
-      const char* ens = tune_env("SCILMM_SPLIT_CHAIN");
-      const char* ecp = tune_env("SCILMM_COMPACT");
-      const bool allow = lookahead && (ens && ens[0] == '1') && !(ecp && ecp[0] == '1') && D->world == 1 && !D->dense_on && S.dense_first >= S.nsuper;
-      int64_t why[3] = {0, 0, 0};
-      for (int32_t l = 1; allow && l + 1 < S.nlevels; ++l) {
-        if (S.level_ptr[l + 1] - S.level_ptr[l] != 1 || S.level_ptr[l + 2] - S.level_ptr[l + 1] != 1) continue;
-        const int32_t sf = S.level_fronts[S.level_ptr[l]], sn = S.level_fronts[S.level_ptr[l + 1]];
-        if (S.sn_start[sf + 1] - S.sn_start[sf] != TM) { why[0]++; continue; }  // tile 0 must be exactly the diagonal block
-        why[2]++;
-        for (int64_t e = S.upd_ptr[sn]; e < S.upd_ptr[sn + 1]; ++e)
-          if (S.upd_src[e] == sf) {
-            crit_t0[l] = S.upd_p0[e] / TM;
-            crit_t1[l] = (S.upd_p1[e] - 1) / TM;
-            D->split_lv[l] = 1;
-          }
-      }
-      if (getenv("SCILMM_VERBOSE")) fprintf(stderr, "[scilmm plan] split candidates: width!=TM %lld, tiles unordered %lld, passed %lld\n", (long long)why[0], (long long)why[1], (long long)why[2]);
-    }
-    // compact combos, same early | late grouping per tile
-    // (each compact combo is cut at tile row TM/2: work item = (tile, half), which owns its cells exclusively)
-    std::vector<ComboDesc> ccd;                              // per tile: [half 0 early | half 0 late | half 1 early | half 1 late]
-    std::vector<int64_t> cptr((size_t)4 * ntiles0 + 1, 0);   // segment 4 g + 2 half + late
-    // Off by default: measured at the 100k pedigree it takes 10 ms out of the dense kernel (62 -> 52 ms) but a
-    // compact combo costs ~10 us of workgroup time (locate, stage, two barriers per K chunk, scatter) against
-    // ~4 us in the padded dense kernel: mode 1 (two items per tile, after the dense kernel) gives factorize
-    // 66 -> 96 ms, mode 2 (32-combo items with private slabs beside the dense kernel) 66 -> 91 ms.  It needs a
-    // software-pipelined item (several combos in flight) to pay off.
-    const char* enoc = tune_env("SCILMM_COMPACT");
-    const bool allow_compact = enoc && (enoc[0] == '1' || enoc[0] == '2');
-    D->compact_mode = allow_compact ? (enoc[0] == '2' ? 2 : 1) : 0;
-    const bool compact_slabs = D->compact_mode == 2;
-    const char* ecf = tune_env("SCILMM_COMPACT_FACTOR");
-    const double compact_factor = ecf ? atof(ecf) : 2.0;
-    struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };  // late: 0 early, 1 late (main), 2 late (rest stream)
+    // "late" = on the main stream, right before the target's potrf: the descendant finished at most `depth` levels below
+    // the target.  A DISTRIBUTED tail target takes all its explicit items late: its panel is read-modify-written by the
+    // batches on their own stream until its late update starts, so nothing else may touch it ahead of time.
+    auto is_late = [&](int32_t d, int32_t sfr) -> bool {
+      return !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr] || (D->world > 1 && sfr >= D->dist_first);
+    };
+    struct Cell { int64_t dst, st, sq; int32_t md, wd, level, late; };  // late: 0 early (side streams), 1 late (main stream)
     std::vector<Cell> cells;
     // The tiles are classified by a few host threads over contiguous tile ranges of about equal combo counts; the
     // per-range outputs are concatenated in tile order, so the plan does not depend on the thread count.
     struct Part {
-      std::vector<ComboDesc> cd, ccd;
-      std::vector<int64_t> dend, dmidv, cend;  // per tile: end of its dense list, its early|late split, 4 compact ends
+      std::vector<ComboDesc> cd;
+      std::vector<int64_t> dend, dmidv;  // per tile: end of its dense list, its early|late split
       std::vector<Cell> cells;
       std::vector<CellCombo> cellcombos;  // device-built cell plan: the small combos themselves
-      int64_t n_sparse = 0, n_compact = 0;
+      int64_t n_sparse = 0;
     };
     // The cell lists are built on the device from the small combos (cellplan.hip.h); SCILMM_HOST_CELLS=1 keeps the
     // host enumeration (same lists up to the order of the contributions inside a group).
@@ -763,9 +829,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     int64_t n_dense_total = 0;
     auto process_range = [&](int64_t gbeg, int64_t gend, Part& Pt) {
     std::vector<ComboDesc>& cd = Pt.cd;
-    std::vector<ComboDesc>& ccd = Pt.ccd;
     std::vector<Cell>& cells = Pt.cells;
-    std::vector<ComboDesc> late_tmp, ctmp[4];
+    std::vector<ComboDesc> late_tmp;
     for (int64_t g = gbeg; g < gend; ++g) {
       const int32_t sfr = S.tile_front[g];
       const int32_t ti = (int32_t)(g - S.tile_base[sfr]);
@@ -778,7 +843,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         const int32_t e = S.combo_pair[c];
         const int32_t d = S.upd_src[e];
         ComboDesc x;
-        x.loff = S.sn_loff[d];
+        x.loff = LOFF[d];
         x.rowoff = S.sn_rowptr[d];
         x.md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
         x.wd = S.sn_start[d + 1] - S.sn_start[d];
@@ -804,43 +869,15 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         }
         if ((double)x.nt * (double)x.nq * (double)x.wd > cell_limit) {
           // "late" = the descendant sits one level below the target (finished only just before this level)
-          const bool late = !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr];
-          // MFMA issue slots on the busiest SIMD: target coordinates (the 16 x 16 blocks inside the spans, eight
-          // waves) against compact coordinates (ceil(nt/16) x ceil(nq/16) blocks dealt to four waves, plus a
-          // fixed cost for the scatter): scattered rows make the spans wide although few blocks carry data
-          const int64_t ksteps = (x.wd + 3) / 4;
-          const int64_t njb = (x.jhi >> 4) - (x.jlo >> 4) + 1, nwv = (x.ihi >> 4) - (x.ilo >> 4) + 1;
-          const int64_t dense_slots = ksteps * njb * (nwv >= 5 ? 2 : 1);
-          const int64_t bt = (x.nt + 15) >> 4, bq = (x.nq + 15) >> 4;
-          const int64_t compact_slots = ksteps * ((bt * bq + 3) / 4) + 24;
-          if (allow_compact && bt * bq <= 16 && (double)compact_slots * compact_factor < (double)dense_slots) {
-            // first descendant row that lands at tile position >= TM/2 (slab mode keeps the combo whole)
-            int32_t tsplit = x.nt;
-            if (!compact_slabs && R0 + TM / 2 < tile_end) {
-              const int32_t* rdx = S.sn_rows.data() + x.rowoff + x.ta;
-              tsplit = (int32_t)(std::lower_bound(rdx, rdx + x.nt, rs[R0 + TM / 2]) - rdx);
-            }
-            for (int h = 0; h < 2; ++h) {
-              ComboDesc y = x;
-              const int32_t t0 = h == 0 ? 0 : tsplit, t1 = h == 0 ? tsplit : x.nt;
-              if (t1 <= t0) continue;
-              y.ta = x.ta + t0;
-              y.nt = t1 - t0;
-              if (x.ip0 >= 0) y.ip0 = x.ip0 + t0;
-              ctmp[2 * h + (late ? 1 : 0)].push_back(y);
-            }
-            Pt.n_compact++;
-          } else {
-            if (late) late_tmp.push_back(x); else cd.push_back(x);
-          }
+          const bool late = is_late(d, sfr);
+          if (late) late_tmp.push_back(x); else cd.push_back(x);
           continue;
         }
         Pt.n_sparse++;
         if (gpu_cells) {
-          const bool clate = !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr];
-          Pt.cellcombos.push_back(CellCombo{x.loff, x.rowoff, S.sn_loff[sfr], S.sn_rowptr[sfr] + R0, x.md, x.wd, x.ta, x.nt, x.p0, x.nq,
+          Pt.cellcombos.push_back(CellCombo{x.loff, x.rowoff, LOFF[sfr], S.sn_rowptr[sfr] + R0, x.md, x.wd, x.ta, x.nt, x.p0, x.nq,
                                             x.ip0, (int32_t)ms, (int32_t)R0, (int32_t)(tile_end - R0), c0s, S.sn_level[sfr],
-                                            clate ? ((D->split_lv[S.sn_level[sfr]] && ti > 0) ? 2 : 1) : 0});
+                                            is_late(d, sfr) ? 1 : 0});
           continue;
         }
         const int32_t* rd = S.sn_rows.data() + x.rowoff;
@@ -850,9 +887,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           for (int32_t q = x.p0; q < x.p0 + x.nq; ++q) {
             const int64_t j = rd[q] - c0s;
             if (R < j) continue;  // strict upper part of the diagonal block is never referenced
-            const bool clate = !lookahead || S.sn_level[d] + depth >= S.sn_level[sfr];
-            cells.push_back(Cell{S.sn_loff[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr],
-                                 clate ? ((D->split_lv[S.sn_level[sfr]] && ti > 0) ? 2 : 1) : 0});
+            cells.push_back(Cell{LOFF[sfr] + j * ms + R, x.loff + t, x.loff + q, x.md, x.wd, S.sn_level[sfr],
+                                 is_late(d, sfr) ? 1 : 0});
           }
         }
       }
@@ -860,11 +896,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       cd.insert(cd.end(), late_tmp.begin(), late_tmp.end());
       late_tmp.clear();
       Pt.dend.push_back((int64_t)cd.size());
-      for (int k4 = 0; k4 < 4; ++k4) {
-        ccd.insert(ccd.end(), ctmp[k4].begin(), ctmp[k4].end());
-        ctmp[k4].clear();
-        Pt.cend.push_back((int64_t)ccd.size());
-      }
     }
     };
     {
@@ -882,9 +913,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       for (unsigned k = 1; k < nth; ++k) pool.emplace_back([&, k]() { process_range(cut[k], cut[k + 1], parts[k]); });
       process_range(cut[0], cut[1], parts[0]);
       for (auto& th : pool) th.join();
-      size_t ncd = 0, nccd = 0, ncell = 0;
-      for (auto& Pt : parts) { ncd += Pt.cd.size(); nccd += Pt.ccd.size(); ncell += Pt.cells.size(); }
-      ccd.reserve(nccd + 1);
+      size_t ncd = 0, ncell = 0;
+      for (auto& Pt : parts) { ncd += Pt.cd.size(); ncell += Pt.cells.size(); }
       cells.reserve(ncell);
       // The dense-path descriptors (18 GB at the 1M config) are NOT concatenated on the host: every part goes straight
       // to its place in the device array, and the host keeps one byte per combo (its cost) for the work-item cuts.
@@ -910,18 +940,15 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       }
       for (unsigned k = 0; k < nth; ++k) {
         Part& Pt = parts[k];
-        const int64_t dbase = dbases[k], cbase = (int64_t)ccd.size();
+        const int64_t dbase = dbases[k];
         for (int64_t g = cut[k]; g < cut[k + 1]; ++g) {
           dmid[g] = dbase + Pt.dmidv[(size_t)(g - cut[k])];
           dptr[g + 1] = dbase + Pt.dend[(size_t)(g - cut[k])];
-          for (int k4 = 0; k4 < 4; ++k4) cptr[4 * g + k4 + 1] = cbase + Pt.cend[(size_t)(4 * (g - cut[k]) + k4)];
         }
         if (!Pt.cd.empty())
           HIPCHK(hipMemcpy(D->d_combos + dbase, Pt.cd.data(), sizeof(ComboDesc) * Pt.cd.size(), hipMemcpyHostToDevice));
-        ccd.insert(ccd.end(), Pt.ccd.begin(), Pt.ccd.end());
         cells.insert(cells.end(), Pt.cells.begin(), Pt.cells.end());
         D->n_sparse_combos += Pt.n_sparse;
-        D->n_compact_combos += Pt.n_compact;
         Part().cd.swap(Pt.cd);
         std::vector<Cell>().swap(Pt.cells);
       }
@@ -1047,8 +1074,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     }
     {
       if (getenv("SCILMM_VERBOSE"))
-        fprintf(stderr, "[scilmm plan] dense combos %lld, compact combos %lld, cell-path combos %lld, cells %lld (early %lld) in %lld target groups\n",
-                (long long)D->n_dense_combos, (long long)D->n_compact_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
+        fprintf(stderr, "[scilmm plan] dense combos %lld, cell-path combos %lld, cells %lld (early %lld) in %lld target groups\n",
+                (long long)D->n_dense_combos, (long long)D->n_sparse_combos, (long long)D->n_cells, (long long)split,
                 (long long)ngroups_total);
       std::vector<Cell>().swap(cells);
       plap("sort/group/upload cells");
@@ -1057,14 +1084,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<int32_t> pslot((size_t)std::max<int64_t>(ntiles, 1), 0), pnseg((size_t)std::max<int64_t>(ntiles, 1), 0);
     std::vector<int32_t> pslot_e(pslot.size(), 0), pnseg_e(pslot.size(), 0), red_tiles_e;
     D->red_ptr_e.assign(S.nlevels + 1, 0);
-    std::vector<UpdWork> work, work_early, cwork, cwork_early;
+    std::vector<UpdWork> work, work_early;
     std::vector<DenseWork> dwork_e, dwork_l;
     D->dwork_e_ptr.assign(S.nlevels + 1, 0);
     D->dwork_l_ptr.assign(S.nlevels + 1, 0);
-    D->work_split.assign(std::max(S.nlevels, 1), 0);
-    D->red_split.assign(std::max(S.nlevels, 1), 0);
-    D->cwork_ptr.assign(S.nlevels + 1, 0);
-    D->cearly_ptr.assign(S.nlevels + 1, 0);
     D->work_ptr.assign(S.nlevels + 1, 0);
     D->early_ptr.assign(S.nlevels + 1, 0);
     D->red_ptr.assign(S.nlevels + 1, 0);
@@ -1075,17 +1098,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // Cost model: a combo costs one fixed unit plus one unit per K-chunk it streams.  Each launch (the early
     // and the late part of a level) is cut into about 4 work items per CU of equal cost, so that one launch
     // fills the chip once with balanced items (late levels of a dense chain: few tiles, long combo lists).
-    auto combo_cost_d = [&](int64_t c) -> int64_t { return cd_cost[(size_t)c]; };
-    auto combo_cost = [&](int64_t c) -> int64_t { return combo_cost_d(c); };
+    auto combo_cost = [&](int64_t c) -> int64_t { return cd_cost[(size_t)c]; };
     // ... but an item never exceeds max_item units (~0.5 ms): the main stream's kernels start in the slots that
     // retiring update items free, so long items starve the per-level chain (300k probe: 2.3 ms per trsm launch)
     const char* emi = tune_env("SCILMM_MAX_ITEM");
     const char* eti = tune_env("SCILMM_TARGET_ITEMS");
     const char* emn = tune_env("SCILMM_MIN_ITEM");
-    const char* eci = tune_env("SCILMM_COMPACT_ITEM");
-    const int64_t compact_item = std::max<int64_t>(1, eci ? atoll(eci) : 32);  // combos per slab-mode compact item
     const char* edi = tune_env("SCILMM_DENSE_ITEMS");
-    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 2048);  // k_dense items per launch (target)
+    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 2048);  // k_dense_a items per launch (target)
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -1123,16 +1143,43 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       for (int32_t f = S.dense_first; f < S.nsuper; ++f)
         for (int32_t c = S.sn_start[f]; c < S.sn_start[f + 1]; ++c) tail_col_front[(size_t)(c - c0t)] = f - S.dense_first;
     }
+    // runs of ACTIVE descendants (those whose true structure reaches target jj) inside [lo, hi)
+    auto active_runs = [&](int32_t jj, int32_t lo, int32_t hi, std::vector<std::pair<int32_t, int32_t>>& runs) -> int64_t {
+      runs.clear();
+      if (hi <= lo) return 0;
+      if (tail_src.empty()) {
+        runs.push_back({lo, hi});
+      } else {
+        const std::vector<int32_t>& src = tail_src[(size_t)jj];
+        auto it = std::lower_bound(src.begin(), src.end(), lo);
+        for (; it != src.end() && *it < hi; ++it) {
+          if (!runs.empty() && runs.back().second == *it) runs.back().second = *it + 1;
+          else runs.push_back({*it, *it + 1});
+        }
+        if (runs.size() > 16) runs = {{runs.front().first, runs.back().second}};  // too fragmented: take the hull
+      }
+      int64_t total = 0;
+      for (auto& r : runs) total += r.second - r.first;
+      return total;
+    };
+    // distributed tail: the far part of an own target's update arrives as one BATCH per source group (see the level
+    // loop of run_factorize); the per-target tile-pair masks are kept for the batch items built after this loop
+    const bool dist = D->world > 1 && D->dist_first < S.nsuper;
+    const int32_t Wg = D->dist_Wg;
+    std::vector<std::vector<uint8_t>> own_pair_on;  // [own tail front (relative)] -> mask, dist mode only
+    if (dist) own_pair_on.resize((size_t)(S.nsuper - S.dense_first));
     int64_t dense_pairs_all = 0, dense_pairs_kept = 0, dense_tiles_all = 0, dense_tiles_kept = 0;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       int64_t total_e = 0, total_l = 0;
       for (int64_t i = S.level_tile_ptr[l]; i < S.level_tile_ptr[l + 1]; ++i) {
         const int32_t g = S.level_tiles[i];
-        for (int64_t c = dptr[g]; c < dmid[g]; ++c) total_e += combo_cost_d(c);
-        for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost_d(c);
+        for (int64_t c = dptr[g]; c < dmid[g]; ++c) total_e += combo_cost(c);
+        for (int64_t c = dmid[g]; c < dptr[g + 1]; ++c) total_l += combo_cost(c);
       }
       // dense tail: the level's (single) front j = dense_first + jj receives every earlier tail front; the last
-      // look_depth of them are "late", the others "early" -- implicit items, one per (pair of tiles, K segment)
+      // look_depth of them are "late", the others "early" -- implicit items, one per (pair of tiles, K segment).
+      // Distributed tail: late = the sources of the target's own group and of the group before it (they arrive while
+      // the chain advances); everything older is applied by the per-group batches.
       int32_t dj = -1, dcnt_e = 0, dcnt_l = 0;
       std::vector<std::pair<int32_t, int32_t>> segs_e, segs_l;  // descendant ranges of the level's dense items
       std::vector<uint8_t> pair_on;                             // per tile pair of the dense target: does it get items
@@ -1146,8 +1193,14 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         if (D->keep_front[fr]) {
           dj = fr;
           const int32_t jj = fr - S.dense_first;
-          dcnt_l = lookahead ? std::min<int32_t>(depth, jj) : jj;
-          dcnt_e = jj - dcnt_l;
+          if (dist) {
+            const int32_t lo = std::max(0, (jj / Wg - 1) * Wg);
+            dcnt_l = jj - lo;
+            dcnt_e = 0;  // (the batches)
+          } else {
+            dcnt_l = lookahead ? std::min<int32_t>(depth, jj) : jj;
+            dcnt_e = jj - dcnt_l;
+          }
           const int64_t ntl = S.tile_base[fr + 1] - S.tile_base[fr];
           // K segments = contiguous ranges of ACTIVE descendants (the same for every tile of the front), about
           // dense_items items per launch: every item writes two 128 KB slabs that k_reduce reads back, so few long
@@ -1156,21 +1209,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           const int64_t want = std::max<int64_t>(1, (dense_items + npairs / 2) / npairs);
           auto build = [&](int32_t lo, int32_t hi, std::vector<std::pair<int32_t, int32_t>>& out) -> int64_t {
             out.clear();
-            if (hi <= lo) return 0;
             std::vector<std::pair<int32_t, int32_t>> runs;
-            if (tail_src.empty()) {
-              runs.push_back({lo, hi});
-            } else {
-              const std::vector<int32_t>& src = tail_src[(size_t)jj];
-              auto it = std::lower_bound(src.begin(), src.end(), lo);
-              for (; it != src.end() && *it < hi; ++it) {
-                if (!runs.empty() && runs.back().second == *it) runs.back().second = *it + 1;
-                else runs.push_back({*it, *it + 1});
-              }
-              if (runs.size() > 16) runs = {{runs.front().first, runs.back().second}};  // too fragmented: take the hull
-            }
-            int64_t total = 0;
-            for (auto& r : runs) total += r.second - r.first;
+            const int64_t total = active_runs(jj, lo, hi, runs);
             if (total == 0) return 0;
             const int64_t nseg = std::min<int64_t>(std::min<int64_t>(64, total), want);
             for (auto& r : runs) {
@@ -1183,8 +1223,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
             }
             return total;
           };
-          const int64_t act_e = build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
-          dense_pairs_all += jj;
+          const int64_t act_e = dist ? 0 : build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
+          dense_pairs_all += dist ? dcnt_l : jj;
           dense_pairs_kept += act_e + act_l;
           // rows of the target that NO active descendant reaches receive nothing but padding: their tile pairs get no
           // items (below the dense region the fronts of one side branch do not reach the columns of the others, nor
@@ -1212,6 +1252,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
             }
           }
           for (uint8_t v : pair_on) { dense_tiles_all += 1; dense_tiles_kept += v; }
+          if (dist) own_pair_on[(size_t)jj] = pair_on;
           total_e += ntl * dunit * act_e;
           total_l += ntl * dunit * act_l;
         }
@@ -1228,44 +1269,18 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         dbase_e.assign((size_t)(S.tile_base[dj + 1] - S.tile_base[dj]), -1);
         dbase_l.assign(dbase_e.size(), -1);
       }
-      // a split level lists its diagonal tile first: the late items / reduce entries of that tile lead the level
       std::vector<int32_t> order(S.level_tiles.begin() + S.level_tile_ptr[l], S.level_tiles.begin() + S.level_tile_ptr[l + 1]);
       // heaviest tiles (most combos) first: the long items of a launch start early
       std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
         return (S.combo_ptr[a + 1] - S.combo_ptr[a]) > (S.combo_ptr[b + 1] - S.combo_ptr[b]);
       });
-      if (D->split_lv[l]) {
-        const int32_t g0 = (int32_t)S.tile_base[S.level_fronts[S.level_ptr[l]]];
-        auto it = std::find(order.begin(), order.end(), g0);
-        if (it != order.end()) std::rotate(order.begin(), it, it + 1);
-        else D->split_lv[l] = 0;
-      }
       for (size_t oi = 0; oi < order.size(); ++oi) {
         const int32_t g = order[oi];
         const size_t fe = work_early.size(), fl = work.size();
         const int64_t ne = cut(g, dptr[g], dmid[g], per_e, work_early);
         const int64_t nl = cut(g, dmid[g], dptr[g + 1], per_l, work);
-        // compact items: one per (tile, half, early | late); they run after the dense kernel and the reduce of
-        // the same launch sequence and own their cells, so they subtract straight into the panel
-        const size_t cfe = cwork_early.size(), cfl = cwork.size();
-        int64_t nce = 0, ncl = 0;
-        if (!compact_slabs) {
-          for (int h = 0; h < 2; ++h) {
-            if (cptr[4 * g + 2 * h + 1] > cptr[4 * g + 2 * h]) cwork_early.push_back(UpdWork{g, h, cptr[4 * g + 2 * h], cptr[4 * g + 2 * h + 1]});
-            if (cptr[4 * g + 2 * h + 2] > cptr[4 * g + 2 * h + 1]) cwork.push_back(UpdWork{g, h, cptr[4 * g + 2 * h + 1], cptr[4 * g + 2 * h + 2]});
-          }
-        } else {
-          // slab mode: whole combos in segments 0 (early) and 1 (late); items of ~compact_item combos each
-          auto ccut = [&](int64_t cb, int64_t ce, std::vector<UpdWork>& out) -> int64_t {
-            int64_t n = 0;
-            for (int64_t a = cb; a < ce; a += compact_item, ++n) out.push_back(UpdWork{g, 0, a, std::min(ce, a + compact_item)});
-            return n;
-          };
-          nce = ccut(cptr[4 * g], cptr[4 * g + 1], cwork_early);
-          ncl = ccut(cptr[4 * g + 1], cptr[4 * g + 2], cwork);
-        }
         // a single dense item of a launch subtracts straight into the panel (the early and the late launch of a
-        // level never overlap in time); two or more go through partial slabs; slab-mode compact items always do
+        // level never overlap in time); two or more go through partial slabs
         // (the implicit dense-tail items of the tile count like explicit ones: dte / dtl of them)
         const bool dtile = dj >= 0 && S.tile_front[g] == dj && pair_on[(size_t)((g - S.tile_base[dj]) / 2)];
         const int64_t dte = dtile ? nde : 0, dtl = dtile ? ndl : 0;
@@ -1273,34 +1288,28 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         const int64_t pde = (ne + dte) >= 2 ? dte : 0, pdl = (nl + dtl) >= 2 ? dtl : 0;
         if (ne == 1 && pe == 0) work_early[fe].slot = -1;
         if (nl == 1 && pl == 0) work[fl].slot = -1;
-        if (pe + nce + pde > 0) {
+        if (pe + pde > 0) {
           pslot_e[g] = (int32_t)slots;
-          pnseg_e[g] = (int32_t)(pe + nce + pde);
+          pnseg_e[g] = (int32_t)(pe + pde);
           red_tiles_e.push_back(g);
           for (int64_t k = 0; k < pe; ++k) work_early[fe + k].slot = (int32_t)(slots + k);
-          for (int64_t k = 0; k < nce; ++k) cwork_early[cfe + k].slot = (int32_t)(slots + pe + k);
-          if (pde > 0) dbase_e[(size_t)(g - S.tile_base[dj])] = (int32_t)(slots + pe + nce);
-          slots += pe + nce + pde;
+          if (pde > 0) dbase_e[(size_t)(g - S.tile_base[dj])] = (int32_t)(slots + pe);
+          slots += pe + pde;
         }
-        if (pl + ncl + pdl > 0) {
+        if (pl + pdl > 0) {
           pslot[g] = (int32_t)slots;
-          pnseg[g] = (int32_t)(pl + ncl + pdl);
+          pnseg[g] = (int32_t)(pl + pdl);
           red_tiles.push_back(g);
           for (int64_t k = 0; k < pl; ++k) work[fl + k].slot = (int32_t)(slots + k);
-          for (int64_t k = 0; k < ncl; ++k) cwork[cfl + k].slot = (int32_t)(slots + pl + k);
-          if (pdl > 0) dbase_l[(size_t)(g - S.tile_base[dj])] = (int32_t)(slots + pl + ncl);
-          slots += pl + ncl + pdl;
-        }
-        if (oi == 0) {  // first tile of the level = the diagonal tile of a split level's front
-          D->work_split[l] = (int64_t)work.size() - D->work_ptr[l];
-          D->red_split[l] = (int64_t)red_tiles.size() - D->red_ptr[l];
+          if (pdl > 0) dbase_l[(size_t)(g - S.tile_base[dj])] = (int32_t)(slots + pl);
+          slots += pl + pdl;
         }
       }
       // Launch order = K-segment major, tile minor: the workgroups resident at any moment then work on the SAME few
       // descendant panels (their target-column rows -- the B operand -- are shared by every tile of the level), so that
       // operand comes out of the L2s / the infinity cache instead of HBM once per tile.  (Slots were assigned above:
       // the partial slabs of a tile stay contiguous whatever the launch order.)
-      if (!D->split_lv[l]) {
+      {
         auto seg_major = [&](std::vector<UpdWork>& v, size_t first) {
           if (v.size() - first < 2) return;
           std::vector<std::pair<int32_t, int32_t>> key(v.size() - first);  // (segment index within its tile, position)
@@ -1319,7 +1328,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       if (dj >= 0) {
         // K-segment major, tile-pair minor (same reason as above); a pair = two vertically adjacent tiles of the front
         const int32_t ntl = (int32_t)(S.tile_base[dj + 1] - S.tile_base[dj]);
-        const int32_t jj = dj - S.dense_first;
         auto emit = [&](std::vector<DenseWork>& out, const std::vector<std::pair<int32_t, int32_t>>& segs, const std::vector<int32_t>& base) {
           for (size_t sg = 0; sg < segs.size(); ++sg) {
             const int32_t k0 = segs[sg].first, k1 = segs[sg].second;
@@ -1342,54 +1350,42 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->lev_cost_l.push_back(total_l);
       D->work_ptr[l + 1] = (int64_t)work.size();
       D->early_ptr[l + 1] = (int64_t)work_early.size();
-      D->cwork_ptr[l + 1] = (int64_t)cwork.size();
-      D->cearly_ptr[l + 1] = (int64_t)cwork_early.size();
       D->red_ptr[l + 1] = (int64_t)red_tiles.size();
       D->red_ptr_e[l + 1] = (int64_t)red_tiles_e.size();
     }
     D->max_slots = std::max<int64_t>(max_slots, 1);
-    {
-      std::vector<int32_t> tl;
-      D->trsm_sptr.assign((size_t)2 * S.nlevels + 1, 0);
-      for (int32_t l = 0; l < S.nlevels; ++l) {
-        if (D->split_lv[l]) {
-          const int64_t lt0 = S.level_tile_ptr[l], lt1 = S.level_tile_ptr[l + 1];
-          const int64_t gb = S.tile_base[S.level_fronts[S.level_ptr[l]]];
-          for (int64_t i = lt0; i < lt1; ++i) {
-            const int64_t rel = S.level_tiles[i] - gb;
-            if (rel >= crit_t0[l] && rel <= crit_t1[l]) tl.push_back(S.level_tiles[i]);
+    if (dist) {
+      // ---- batches of the distributed tail: batch g = the contribution of source group g (tail fronts
+      //      [g Wg, (g+1) Wg)) to every own target that lies at least two groups later -- one item per (target, tile
+      //      pair), K = the hull of the group's active sources, subtracted straight from the panel (batches run one
+      //      after the other on one stream, and a target's late update waits for its last batch)
+      const int32_t nT = S.nsuper - S.dense_first;
+      const int32_t ngroups = (nT + Wg - 1) / Wg;
+      std::vector<DenseWork> dwork_b;
+      D->dbatch_ptr.assign((size_t)ngroups + 1, 0);
+      std::vector<std::pair<int32_t, int32_t>> runs;
+      for (int32_t g = 0; g < ngroups; ++g) {
+        for (int32_t jj = (g + 2) * Wg; jj < nT; ++jj) {
+          const int32_t fr = S.dense_first + jj;
+          if (!D->keep_front[fr]) continue;
+          if (active_runs(jj, g * Wg, std::min((g + 1) * Wg, nT), runs) == 0) continue;
+          const int32_t k0 = runs.front().first, k1 = runs.back().second;
+          const int32_t ntl = (int32_t)(S.tile_base[fr + 1] - S.tile_base[fr]);
+          const std::vector<uint8_t>& pon = own_pair_on[(size_t)jj];
+          for (int32_t q = 0; q < ntl; q += 2) {
+            if (!pon.empty() && !pon[(size_t)(q / 2)]) continue;
+            dwork_b.push_back(DenseWork{fr, q, std::min<int32_t>(2, ntl - q), k0, k1, -1, -1, 0});
           }
-          D->trsm_sptr[2 * l + 1] = (int64_t)tl.size();
-          for (int64_t i = lt0; i < lt1; ++i) {
-            const int64_t rel = S.level_tiles[i] - gb;
-            if (!(rel >= crit_t0[l] && rel <= crit_t1[l])) tl.push_back(S.level_tiles[i]);
-          }
-        } else {
-          D->trsm_sptr[2 * l + 1] = (int64_t)tl.size();
         }
-        D->trsm_sptr[2 * l + 2] = (int64_t)tl.size();
+        D->dbatch_ptr[(size_t)g + 1] = (int64_t)dwork_b.size();
       }
-      if (tl.empty()) tl.push_back(0);
-      if ((st = upload(sym, D, tl, &tmp)) != SCILMM_OK) return st;
-      D->d_trsm_split = (int32_t*)tmp;
-      if (getenv("SCILMM_VERBOSE")) {
-        int64_t nsp = 0;
-        for (int32_t l = 0; l < S.nlevels; ++l) nsp += D->split_lv[l];
-        fprintf(stderr, "[scilmm plan] split chain levels: %lld of %d\n", (long long)nsp, S.nlevels);
-      }
-    }
-    {
-      if (ccd.empty()) ccd.push_back(ComboDesc{});
-      const ComboDesc* dcc;
-      if ((st = upload(sym, D, ccd, &dcc)) != SCILMM_OK) return st;
-      D->d_ccombos = (ComboDesc*)dcc;
-      if (cwork.empty()) cwork.push_back(UpdWork{0, 0, 0, 0});
-      if (cwork_early.empty()) cwork_early.push_back(UpdWork{0, 0, 0, 0});
-      const UpdWork* dcw;
-      if ((st = upload(sym, D, cwork, &dcw)) != SCILMM_OK) return st;
-      D->d_cwork = (UpdWork*)dcw;
-      if ((st = upload(sym, D, cwork_early, &dcw)) != SCILMM_OK) return st;
-      D->d_cwork_early = (UpdWork*)dcw;
+      if (dwork_b.empty()) dwork_b.push_back(DenseWork{});
+      const DenseWork* ddb;
+      if ((st = upload(sym, D, dwork_b, &ddb)) != SCILMM_OK) return st;
+      D->d_dwork_b = (DenseWork*)ddb;
+      if (getenv("SCILMM_VERBOSE"))
+        fprintf(stderr, "[scilmm plan] rank %d: %lld batch items in %d source groups of %d tail panels\n", D->rank,
+                (long long)D->dbatch_ptr[(size_t)ngroups], ngroups, Wg);
     }
     {
       if (dwork_e.empty()) dwork_e.push_back(DenseWork{});
@@ -1403,10 +1399,9 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         fprintf(stderr, "[scilmm plan] dense tail: %lld of %lld (target, descendant) panel pairs carry true entries, %lld of %lld target tile pairs are reached by a descendant (the others are padding only and skipped)\n",
                 (long long)dense_pairs_kept, (long long)dense_pairs_all, (long long)dense_tiles_kept, (long long)dense_tiles_all);
       if (getenv("SCILMM_VERBOSE"))
-        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense, MFMA form %d%s)\n",
+        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense_a)\n",
                 S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,
-                (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels], D->dense_mf,
-                D->dense_mf != 16 ? "" : D->dense_glds == 2 ? ", A from registers, B by LDS-DMA" : D->dense_glds ? ", LDS-DMA staging" : "");
+                (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels]);
     }
     if (work_early.empty()) work_early.push_back(UpdWork{0, -1, 0, 0});
     {
@@ -1454,6 +1449,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* enc = tune_env("SCILMM_NO_CHAIN");
     int32_t T = l0 < S.nlevels ? S.level_ptr[S.nlevels] - S.level_ptr[l0] : 0;
     if (S.nlevels - l0 < 4 || (enc && enc[0] == '1')) T = 0;
+    if (D->world > 1) T = 0;  // a distributed factor is swept level by level with a collective per tail block (run_rhs)
     D->chain_T = T;
     D->chain_l0 = l0;
     if (T > 0) {
@@ -1620,21 +1616,9 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense_g, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_update3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_update3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-#ifdef SCILMM_DIAG
-  HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_update<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-#endif
-  HIPCHK(hipFuncSetAttribute((const void*)k_update<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
   return SCILMM_OK;
 }
@@ -1642,6 +1626,10 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
 int ensure_work(scilmm_symbolic* sym, Dev* D) {
   const Symbolic& S = *sym->S;
   size_t bytes = (size_t)std::max(S.n, 1) * RPMAX * sizeof(double);
+  if (D->world > 1 && !D->work_external) {
+    sym->err = "multi-GPU: scilmm_dist_set_work has not been called (the sweeps' buffers must be addressable by the communication layer)";
+    return SCILMM_ERR_STATE;
+  }
   if (!D->W) HIPCHK(hipMalloc((void**)&D->W, bytes));
   if (!D->X) HIPCHK(hipMalloc((void**)&D->X, bytes));
   return set_attrs(sym, D);
@@ -1697,16 +1685,21 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     sym->err = "multi-GPU: scilmm_dist_init was called without a communication callback / stream";
     return SCILMM_ERR_STATE;
   }
+  if (D->world > 1 && !fac->external) {
+    sym->err = "multi-GPU: the factor must live in caller-owned storage (scilmm_factor_create_external)";
+    return SCILMM_ERR_STATE;
+  }
   {
     int stc = set_attrs(sym, D);
     if (stc != SCILMM_OK) return stc;
   }
+  const bool dist = D->world > 1 && D->dist_first < S.nsuper;
   const size_t sm_upd = sizeof(double) * (size_t)(2 * KC * LDA + 2 * KC * LDB) + sizeof(int32_t) * TM;
   const size_t sm_potrf = sizeof(double) * (size_t)((NB / 2) * (NB + 1) + NJB * 16 * 17);
   hipStream_t st = D->stream;
   int64_t launches = 0;
   HIPCHK(hipEventRecord(D->ev[0], st));
-  HIPCHK(hipMemsetAsync(fac->L, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nnzL_stored, 1), st));
+  HIPCHK(hipMemsetAsync(fac->L, 0, sizeof(double) * (size_t)std::max<int64_t>(D->nL_local, 1), st));
   int32_t big = 0x7fffffff;
   HIPCHK(hipMemcpyAsync(fac->status, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
   ValPtrs gen{}, dia{};
@@ -1734,10 +1727,12 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   HIPCHK(hipStreamWaitEvent(D->side, D->ev_asm, 0));
   HIPCHK(hipStreamWaitEvent(D->side2, D->ev_asm, 0));
   if (D->side3) HIPCHK(hipStreamWaitEvent(D->side3, D->ev_asm, 0));
-  for (auto& cs : D->cside)
-    if (cs) HIPCHK(hipStreamWaitEvent(cs, D->ev_asm, 0));
-  HIPCHK(hipStreamWaitEvent(D->rest, D->ev_asm, 0));
   if (D->outside_st) HIPCHK(hipStreamWaitEvent(D->outside_st, D->ev_asm, 0));
+  if (dist) {
+    // nothing may land in the ring (or be read-modify-written by a batch) before the storage is cleared and assembled
+    HIPCHK(hipStreamWaitEvent(D->bstream, D->ev_asm, 0));
+    HIPCHK(hipStreamWaitEvent(D->comm, D->ev_asm, 0));
+  }
   const bool prof = D->profiling;
   constexpr int PE = 12;  // profiling events per level
   if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
@@ -1745,67 +1740,36 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     D->pev.resize((size_t)PE * S.nlevels, nullptr);
     for (size_t i = old; i < D->pev.size(); ++i) HIPCHK(hipEventCreate(&D->pev[i]));
   }
+  // A dispatch counts WORK-ITEMS in 32 bits: cnt workgroups of `threads` threads must stay below 2^32 of them.
+  // Every launch helper below cuts its grid at max_groups(threads) workgroups (k_outside was the only
+  // chunked launch; the 1M plan has single launches of several million workgroups).
+  auto max_groups = [](unsigned threads) -> int64_t { return (int64_t)(((uint64_t)1 << 32) / threads) - 1; };
   auto launch_update = [&](hipStream_t stream, const UpdWork* work, int64_t cnt, double* scratch_half) {
 #ifdef SCILMM_DIAG
     if (D->ablate == 4) return;  // timing ablation: no explicit MFMA update items at all (WRONG numbers)
-    if (D->use_mfma && D->ablate == 1) {
-      hipLaunchKernelGGL((k_update<true, 1>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-      launches++;
-      return;
-    }
-    if (D->use_mfma && D->ablate == 2) {
-      hipLaunchKernelGGL((k_update<true, 2>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-      launches++;
-      return;
-    }
 #endif
-    if (D->update_variant == 3) {
+    for (int64_t o = 0; o < cnt; o += max_groups(UPD_THREADS)) {
+      const unsigned c = (unsigned)std::min<int64_t>(cnt - o, max_groups(UPD_THREADS));
       if (D->use_mfma)
-        hipLaunchKernelGGL((k_update3<true>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+        hipLaunchKernelGGL((k_update2<true>), dim3(c), dim3(UPD_THREADS), sm_upd, stream, D->v, work + o, D->d_combos, fac->L, scratch_half);
       else
-        hipLaunchKernelGGL((k_update3<false>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
+        hipLaunchKernelGGL((k_update2<false>), dim3(c), dim3(UPD_THREADS), sm_upd, stream, D->v, work + o, D->d_combos, fac->L, scratch_half);
       launches++;
-      return;
     }
-    if (D->use_mfma && D->update_variant == 2)
-      hipLaunchKernelGGL((k_update2<true>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-    else if (D->use_mfma)
-      hipLaunchKernelGGL((k_update<true, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-    else if (D->update_variant == 2)
-      hipLaunchKernelGGL((k_update2<false>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-    else
-      hipLaunchKernelGGL((k_update<false, 0>), dim3((unsigned)cnt), dim3(UPD_THREADS), sm_upd, stream, D->v, work, D->d_combos, fac->L, scratch_half);
-    launches++;
   };
-  const size_t sm_dense = sizeof(double) * (size_t)(2 * KC * LDA2 + 2 * KC * LDB);
   auto launch_dense = [&](hipStream_t stream, const DenseWork* dw, int64_t cnt, double* scratch_half) {
-    if (cnt <= 0) return;
-    if (D->use_mfma && D->front_bits == 32)
-      hipLaunchKernelGGL(k_dense32, dim3((unsigned)cnt), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
-                         S.dense_first, dw, fac->L, scratch_half);
-    else if (!D->use_mfma)
-      hipLaunchKernelGGL((k_dense<4, false>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
-    else if (D->dense_mf == 4)
-      hipLaunchKernelGGL((k_dense<4, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
-    else if (D->dense_glds == 2)
-      hipLaunchKernelGGL(k_dense_a, dim3((unsigned)cnt), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw,
-                         fac->L, scratch_half, (const double*)D->d_zeros);
-    else if (D->dense_glds)
-      hipLaunchKernelGGL(k_dense_g, dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half,
-                         (const double*)D->d_zeros);
-    else
-      hipLaunchKernelGGL((k_dense<16, true>), dim3((unsigned)cnt), dim3(512), sm_dense, stream, D->v, S.dense_first, dw, fac->L, scratch_half);
-    launches++;
+    for (int64_t o = 0; o < cnt; o += max_groups(512)) {
+      const unsigned c = (unsigned)std::min<int64_t>(cnt - o, max_groups(512));
+      if (D->front_bits == 32)
+        hipLaunchKernelGGL(k_dense32, dim3(c), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
+                           S.dense_first, dw + o, fac->L, scratch_half);
+      else
+        hipLaunchKernelGGL(k_dense_a, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
+                           fac->L, scratch_half, (const double*)D->d_zeros);
+      launches++;
+    }
   };
   const size_t half = (size_t)D->max_slots * TM * NB;
-  auto launch_compact = [&](hipStream_t stream, const UpdWork* cw, int64_t cnt, double* slabs = nullptr) {
-    if (cnt <= 0) return;
-    if (D->use_mfma)
-      hipLaunchKernelGGL(k_update_compact<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L, slabs);
-    else
-      hipLaunchKernelGGL(k_update_compact<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, cw, (const ComboDesc*)D->d_ccombos, fac->L, slabs);
-    launches++;
-  };
   auto launch_cells = [&](hipStream_t stream, int which, int32_t l) {
     const Dev::CellSet& CS = D->cellset[which];
     const int64_t u0 = CS.level_ptr[l], u1 = CS.level_ptr[l + 1];
@@ -1815,76 +1779,49 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
 #endif
     const int64_t nshort = CS.level_short[l], nlong = (u1 - u0) - nshort;
     const int64_t nblk = (nshort + 255) / 256 + (nlong + 3) / 4;
+    if (nblk > max_groups(256)) {  // 2^24 workgroups = 4e9 cells of one level: beyond any plan the cell limit admits
+      sym->err = "cell plan: one level has more target cells than a dispatch can hold";
+      return;
+    }
     hipLaunchKernelGGL(k_sparse_cells, dim3((unsigned)nblk), dim3(256), 0, stream, u0, nshort, u1 - u0, (const int64_t*)CS.dst,
                        (const int64_t*)CS.grp, (const int64_t*)CS.srct, (const int64_t*)CS.srcq, (const int32_t*)CS.md,
                        (const int32_t*)CS.wd, fac->L);
     launches++;
   };
+  auto launch_reduce = [&](hipStream_t stream, const int32_t* tiles, int64_t cnt, const int32_t* pslot, const int32_t* pnseg,
+                           const double* slabs) {
+    const int64_t per = max_groups(128) / (NB / 4);  // tiles per dispatch
+    for (int64_t o = 0; o < cnt; o += per) {
+      const int64_t c = std::min(cnt - o, per);
+      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * c)), dim3(128), 0, stream, D->v, tiles + o, pslot, pnseg, slabs, fac->L);
+      launches++;
+    }
+  };
   auto has_early = [&](int32_t l) -> bool {
-    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cearly_ptr[l + 1] > D->cearly_ptr[l] ||
-           D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l] || D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l];
+    return D->early_ptr[l + 1] > D->early_ptr[l] || D->cellset[0].level_ptr[l + 1] > D->cellset[0].level_ptr[l] ||
+           D->dwork_e_ptr[l + 1] > D->dwork_e_ptr[l];
   };
   // Look-ahead: the EARLY part of level l+1 (descendants finished at levels <= l-1) runs on the side stream
   // while the main stream works through level l's latency-bound tail (late update, reduce, cells, potrf, trsm).
   auto launch_early = [&](int32_t l) -> int {
     const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
     if (!has_early(l)) return SCILMM_OK;
-    // (multi-GPU: a rank's own chain levels are `world` apart -- alternate the side streams over ITS levels)
-    const int sidx = (D->world > 1 && l >= D->dist_l0) ? ((l - D->dist_l0) / D->world) % D->nside : l % D->nside;
+    const int sidx = l % D->nside;
     hipStream_t sd = sidx == 0 ? D->side : (sidx == 1 ? D->side2 : D->side3);
     // its youngest descendants sit look_depth + 1 levels below
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
     // tail targets: the atomic contributions of the prelude (k_outside) must have landed before anything else
     // reads-modifies-writes a tail panel (the event has been recorded: these launches are deferred until it is)
-    if (D->outside_on && l >= D->tail_level) {
-      HIPCHK(hipStreamWaitEvent(sd, D->out_ev, 0));
-      for (auto& cs : D->cside)
-        if (cs) HIPCHK(hipStreamWaitEvent(cs, D->out_ev, 0));
-    }
-    const int64_t ncw_e = D->cearly_ptr[l + 1] - D->cearly_ptr[l];
-    const bool slab_compact = D->compact_mode == 2 && ncw_e > 0 && D->cside[l & 1];
-    if (slab_compact) {
-      // the compact items write their own slabs of the same scratch region: they run BESIDE the dense kernel on
-      // their own stream (same dependencies; the region is free once early(l - nside) has been folded)
-      hipStream_t cs = D->cside[l & 1];
-      if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(cs, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
-      if (l >= D->nside) HIPCHK(hipStreamWaitEvent(cs, D->lev_ev[2 * (l - D->nside) + 1], 0));
-      launch_compact(cs, D->d_cwork_early + D->cearly_ptr[l], ncw_e, D->scratch + (size_t)sidx * half);
-      HIPCHK(hipEventRecord(D->chain_ev[3 * l], cs));
-    }
+    if (D->outside_on && l >= D->tail_level) HIPCHK(hipStreamWaitEvent(sd, D->out_ev, 0));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 8], sd));
     launch_dense(sd, D->d_dwork_e + D->dwork_e_ptr[l], D->dwork_e_ptr[l + 1] - D->dwork_e_ptr[l], D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 9], sd));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 6], sd));
-    if (slab_compact) HIPCHK(hipStreamWaitEvent(sd, D->chain_ev[3 * l], 0));
-    {
-      // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
-      const int64_t q0 = D->red_ptr_e[l], q1 = D->red_ptr_e[l + 1];
-      if (q1 > q0) {
-        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (q1 - q0))), dim3(128), 0, sd, D->v, D->d_red_tiles_e + q0,
-                           D->d_tile_pslot_e, D->d_tile_pnseg_e, (const double*)(D->scratch + (size_t)sidx * half), fac->L);
-        launches++;
-      }
-    }
-    if (D->compact_mode == 2) {
-      launch_cells(sd, 0, l);
-      HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
-      return SCILMM_OK;
-    }
-    if (ncw_e > 0 && D->cside[l & 1]) {
-      // compact items (few, long) and the cells of the level move to their own stream: the side stream goes on
-      // with the dense update of the level after next while they run (same panels: ordered by the event)
-      hipStream_t cs = D->cside[l & 1];
-      HIPCHK(hipEventRecord(D->chain_ev[3 * l], sd));
-      HIPCHK(hipStreamWaitEvent(cs, D->chain_ev[3 * l], 0));
-      launch_compact(cs, D->d_cwork_early + D->cearly_ptr[l], ncw_e);
-      launch_cells(cs, 0, l);
-      HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], cs));
-      return SCILMM_OK;
-    }
-    launch_compact(sd, D->d_cwork_early + D->cearly_ptr[l], ncw_e);
+    // fold the early partial slabs on the side stream as well: the main stream keeps only its own (rare) ones
+    launch_reduce(sd, D->d_red_tiles_e + D->red_ptr_e[l], D->red_ptr_e[l + 1] - D->red_ptr_e[l], D->d_tile_pslot_e, D->d_tile_pnseg_e,
+                  (const double*)(D->scratch + (size_t)sidx * half));
     launch_cells(sd, 0, l);  // early cells: same stream, after the early MFMA update of the same panels
     HIPCHK(hipEventRecord(D->lev_ev[2 * l + 1], sd));
     return SCILMM_OK;
@@ -1896,9 +1833,11 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     int rc = launch_early(l);
     if (rc != SCILMM_OK) return rc;
   }
+  const int32_t nT = S.nsuper - D->dist_first, Wg = D->dist_Wg;
+  int32_t last_tail_level = -1;
   for (int32_t l = 0; l < S.nlevels; ++l) {
-    const int64_t t0 = S.level_tile_ptr[l], t1 = S.level_tile_ptr[l + 1];
-    const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];
+    const int64_t t0 = D->lv_tile_ptr[l], t1 = D->lv_tile_ptr[l + 1];
+    const int32_t f0 = D->lv_ptr[l], f1 = D->lv_ptr[l + 1];
     double* sh = D->scratch + (size_t)3 * half;
     // early(l + depth) may start as soon as level l-1 is finished: issue it before this level's own kernels
     if (l >= 1 && l + D->look_depth < S.nlevels && !(l < D->tail_level && deferred(l + D->look_depth))) {
@@ -1907,126 +1846,85 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     }
     if (D->outside_on && l == D->tail_level) HIPCHK(hipStreamWaitEvent(st, D->out_ev, 0));
     const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
-    const int64_t r0 = D->red_ptr[l], r1 = D->red_ptr[l + 1];
-    auto launch_reduce = [&](hipStream_t stream, int64_t q0, int64_t q1) {
-      if (q1 <= q0) return;
-      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((NB / 4) * (q1 - q0))), dim3(128), 0, stream, D->v, D->d_red_tiles + q0, D->d_tile_pslot,
-                         D->d_tile_pnseg, (const double*)sh, fac->L);
+    const int32_t tf = dist ? D->tail_of_level[l] : -1;  // the distributed front of this level
+    const int32_t jj = tf >= 0 ? tf - D->dist_first : -1, grp = tf >= 0 ? jj / Wg : -1;
+    if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
+    if (tf >= 0 && D->keep_front[tf]) {
+      // own tail panel: every batch up to group grp - 2 has been applied to it; its late sources -- the panels of the
+      // group before and of its own group so far -- have arrived (own ones: their level event)
+      if (grp >= 2) HIPCHK(hipStreamWaitEvent(st, D->batch_ev[grp - 2], 0));
+      for (int32_t q = std::max(0, (grp - 1) * Wg); q < jj; ++q) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * S.sn_level[D->dist_first + q]], 0));
+    }
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
+    if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 10], st));
+    launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], D->dwork_l_ptr[l + 1] - D->dwork_l_ptr[l], sh);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 11], st));
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
+    launch_reduce(st, D->d_red_tiles + D->red_ptr[l], D->red_ptr[l + 1] - D->red_ptr[l], D->d_tile_pslot, D->d_tile_pnseg, (const double*)sh);
+    launch_cells(st, 1, l);
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
+    if (f1 > f0) {
+      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
+                         fac->invD, fac->logd, fac->status);
       launches++;
-    };
-    auto launch_trsm = [&](hipStream_t stream, const int32_t* tiles, int64_t cnt) {
-      if (cnt <= 0) return;
-      if (D->use_mfma && D->update_variant == 3)
-        hipLaunchKernelGGL(k_trsm4, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
-      else if (D->use_mfma)
-        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
+    }
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
+    if (t1 > t0) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD);
       else
-        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)cnt), dim3(256), 0, stream, D->v, tiles, fac->L, fac->invD);
+        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD);
       launches++;
-    };
-    // a level that follows a split level: its predecessor's tail (the other tiles' trsm) ended on the rest stream
-    const bool prev_split = l >= 1 && D->split_lv[l - 1];
-    const bool dist_chain = D->world > 1 && l >= D->dist_l0;
-    if (!D->split_lv[l]) {
-      if (D->own_level[l]) {
-        if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
-        if (prev_split) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - 1)], 0));
-        if (dist_chain) {
-          // the late items read the panels of the last look_depth levels, which other ranks produced: wait for
-          // their arrival (events of the comm stream; for this rank's own older panels the wait is a no-op)
-          for (int32_t back = 1; back <= D->look_depth && back <= l; ++back) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - back)], 0));
-        }
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
-        if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 10], st));
-        launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], D->dwork_l_ptr[l + 1] - D->dwork_l_ptr[l], sh);
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 11], st));
-        if (D->compact_mode == 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l], sh);
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
-        launch_reduce(st, r0, r1);
-        if (D->compact_mode != 2) launch_compact(st, D->d_cwork + D->cwork_ptr[l], D->cwork_ptr[l + 1] - D->cwork_ptr[l]);
-        launch_cells(st, 1, l);
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
-        if (f1 > f0) {
-          hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
-                             fac->invD, fac->logd, fac->status);
-          launches++;
-        }
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
-        launch_trsm(st, D->d_level_tiles + t0, t1 - t0);
-        if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
-      } else if (prof) {
-        for (int q = 0; q < 5; ++q) HIPCHK(hipEventRecord(D->pev[PE * l + q], st));
-      }
-      if (!dist_chain) {
-        HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
-      } else {
-        // ---- distributed chain level: the owner's panel (+ inverse diagonal block + log-sum) goes to every rank
-        const int32_t sfr = S.level_fronts[f0];
-        const int32_t root = (l - D->dist_l0) % D->world;
-        if (l == D->dist_l0 && l > 0) HIPCHK(hipStreamWaitEvent(D->comm, D->lev_ev[2 * (l - 1)], 0));  // local prelude (and assembly) complete
-        if (D->own_level[l]) {
-          HIPCHK(hipEventRecord(D->done_ev[l], st));
-          HIPCHK(hipStreamWaitEvent(D->comm, D->done_ev[l], 0));
-        }
-        const int64_t pm = S.sn_rowptr[sfr + 1] - S.sn_rowptr[sfr], pw = S.sn_start[sfr + 1] - S.sn_start[sfr];
-        int rcm = sym->comm_fn(sym->comm_ctx, 0, 0, S.sn_loff[sfr], pm * pw, root);
-        if (rcm == 0) rcm = sym->comm_fn(sym->comm_ctx, 0, 1, S.inv_off[sfr], pw * pw, root);
-        if (rcm == 0) rcm = sym->comm_fn(sym->comm_ctx, 0, 2, sfr, 1, root);
-        if (rcm != 0) {
-          sym->err = "multi-GPU: the communication callback failed";
-          return SCILMM_ERR_DEVICE;
-        }
-        HIPCHK(hipEventRecord(D->lev_ev[2 * l], D->comm));
-      }
+    }
+    if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
+    if (tf < 0) {
+      HIPCHK(hipEventRecord(D->lev_ev[2 * l], st));
     } else {
-      // ---- split chain level.  Main stream: late update of the diagonal tile, potrf, then trsm of the tiles the
-      //      NEXT diagonal block is updated from.  Rest stream: late update of the other tiles, then their trsm.
-      hipStream_t rs = D->rest;
-      hipEvent_t e_potrf = D->chain_ev[3 * l + 0], e_lur = D->chain_ev[3 * l + 1], e_t1 = D->chain_ev[3 * l + 2];
-      const int64_t ws = D->work_split[l], rsplit = D->red_split[l];
-      // main: needs early(l); level l-2 complete (its panels are read by the late items: depth 2); the critical
-      // rows of level l-1 (same stream if l-1 was split, else the whole level l-1 ran on this stream)
-      if (has_early(l)) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * l + 1], 0));
-      for (int32_t back = 2; back <= D->look_depth && back <= l; ++back)
-        if (D->split_lv[l - back]) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (l - back)], 0));
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
-      if (ws > 0) launch_update(st, D->d_work + w0, ws, sh);
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
-      launch_reduce(st, r0, r0 + rsplit);
-      launch_cells(st, 1, l);
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
-      hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L, fac->invD,
-                         fac->logd, fac->status);
-      launches++;
-      HIPCHK(hipEventRecord(e_potrf, st));
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
-      // rest: the other tiles of panel l.  Needs early(l) and ALL of level l-1 (and older late levels).
-      if (has_early(l)) HIPCHK(hipStreamWaitEvent(rs, D->lev_ev[2 * l + 1], 0));
-      for (int32_t back = 1; back <= D->look_depth && back <= l; ++back) HIPCHK(hipStreamWaitEvent(rs, D->lev_ev[2 * (l - back)], 0));
-      if (w1 > w0 + ws) launch_update(rs, D->d_work + w0 + ws, w1 - w0 - ws, sh);
-      launch_reduce(rs, r0 + rsplit, r1);
-      launch_cells(rs, 2, l);
-      HIPCHK(hipEventRecord(e_lur, rs));
-      // main: critical trsm tiles (their late update ran on the rest stream)
-      HIPCHK(hipStreamWaitEvent(st, e_lur, 0));
-      launch_trsm(st, D->d_trsm_split + D->trsm_sptr[2 * l], D->trsm_sptr[2 * l + 1] - D->trsm_sptr[2 * l]);
-      HIPCHK(hipEventRecord(e_t1, st));
-      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
-      // rest: the remaining trsm tiles; the level is complete when both parts are
-      HIPCHK(hipStreamWaitEvent(rs, e_potrf, 0));
-      launch_trsm(rs, D->d_trsm_split + D->trsm_sptr[2 * l + 1], D->trsm_sptr[2 * l + 2] - D->trsm_sptr[2 * l + 1]);
-      HIPCHK(hipStreamWaitEvent(rs, e_t1, 0));
-      HIPCHK(hipEventRecord(D->lev_ev[2 * l], rs));
+      // ---- level with a distributed tail panel: the owner's panel (+ inverse diagonal block + log-sum) goes to every
+      //      rank -- into the receiver's ring slot.  The level is complete (lev_ev) when the panel has arrived AND this
+      //      rank's own kernels of the level (its prelude fronts) have finished.
+      const int32_t root = jj % D->world;
+      HIPCHK(hipEventRecord(D->done_ev[l], st));
+      HIPCHK(hipStreamWaitEvent(D->comm, D->done_ev[l], 0));
+      if (!D->keep_front[tf]) {
+        // ring re-use: the slot's previous occupant (panel jj - G, group gd) must have been consumed -- by its batch and by
+        // the late updates of this rank's targets of groups gd and gd + 1
+        const int32_t gd = (jj - D->dist_G) / Wg;
+        if (jj >= D->dist_G) {
+          HIPCHK(hipStreamWaitEvent(D->comm, D->batch_ev[gd], 0));
+          for (int32_t q = std::min<int32_t>(gd + 1, (int32_t)D->last_own_level.size() - 1); q >= 0; --q)
+            if (D->last_own_level[q] >= 0) {
+              HIPCHK(hipStreamWaitEvent(D->comm, D->done_ev[D->last_own_level[q]], 0));
+              break;
+            }
+        }
+      }
+      const int64_t pm = S.sn_rowptr[tf + 1] - S.sn_rowptr[tf], pw = S.sn_start[tf + 1] - S.sn_start[tf];
+      int rcm = sym->comm_fn(sym->comm_ctx, 0, 0, D->loff[tf], pm * pw, root);
+      if (rcm == 0) rcm = sym->comm_fn(sym->comm_ctx, 0, 1, S.inv_off[tf], pw * pw, root);
+      if (rcm == 0) rcm = sym->comm_fn(sym->comm_ctx, 0, 2, tf, 1, root);
+      if (rcm != 0) {
+        sym->err = "multi-GPU: the communication callback failed";
+        return SCILMM_ERR_DEVICE;
+      }
+      HIPCHK(hipEventRecord(D->lev_ev[2 * l], D->comm));
+      last_tail_level = l;
+      if ((jj + 1) % Wg == 0 || jj == nT - 1) {
+        // ---- source group grp is complete on this rank: its batch (every own target at least two groups ahead)
+        hipStream_t bs = D->bstream;
+        for (int32_t q = grp * Wg; q <= jj; ++q) HIPCHK(hipStreamWaitEvent(bs, D->lev_ev[2 * S.sn_level[D->dist_first + q]], 0));
+        if (D->outside_on) HIPCHK(hipStreamWaitEvent(bs, D->out_ev, 0));
+        launch_dense(bs, D->d_dwork_b + D->dbatch_ptr[grp], D->dbatch_ptr[grp + 1] - D->dbatch_ptr[grp], nullptr);
+        HIPCHK(hipEventRecord(D->batch_ev[grp], bs));
+      }
     }
     if (D->outside_on && l == D->tail_level - 1) {
       // ---- every prelude front below the tail's first level is final: its contribution to the tail, in ITS
       //      coordinates, with atomic subtraction (k_outside); nothing else touches a tail panel meanwhile
       HIPCHK(hipStreamWaitEvent(D->outside_st, D->lev_ev[2 * l], 0));
-      // (a launch carries at most 2^23 items: the dispatch packet counts WORK-ITEMS in 32 bits, 2^24 workgroups of 256
-      // threads would overflow it -- the 1M config with a short tail has 21M items)
-      for (int64_t o0 = 0; o0 < D->n_owork; o0 += (int64_t)1 << 23) {
-        const unsigned cnt = (unsigned)std::min<int64_t>((int64_t)1 << 23, D->n_owork - o0);
+      for (int64_t o0 = 0; o0 < D->n_owork; o0 += max_groups(256)) {
+        const unsigned cnt = (unsigned)std::min<int64_t>(max_groups(256), D->n_owork - o0);
         const OutsideWork* ow = (const OutsideWork*)D->d_owork + o0;
 #ifdef SCILMM_DIAG
         if (D->ablate == 6)  // timing ablations: no scatter / plain stores (WRONG numbers)
@@ -2054,7 +1952,23 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       }
     }
   }
-  if (D->world > 1 && S.nlevels > D->dist_l0) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * (S.nlevels - 1)], 0));
+  if (!sym->err.empty() && sym->err.rfind("cell plan:", 0) == 0) return SCILMM_ERR_ARG;
+  if (dist) {
+    if (last_tail_level >= 0) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * last_tail_level], 0));
+    if (!D->batch_ev.empty()) HIPCHK(hipStreamWaitEvent(st, D->batch_ev.back(), 0));
+    // the status word (first non-positive pivot, or "none") is written by the owner of the failing panel only: every
+    // rank takes the minimum, so that all of them report SCILMM_ERR_NOT_PD together
+    hipLaunchKernelGGL(k_status_pack, dim3(1), dim3(1), 0, st, (const int32_t*)fac->status, fac->logd + S.nsuper);
+    HIPCHK(hipEventRecord(D->ev_x0, st));
+    HIPCHK(hipStreamWaitEvent(D->comm, D->ev_x0, 0));
+    if (sym->comm_fn(sym->comm_ctx, 2, 2, S.nsuper, 1, 0) != 0) {
+      sym->err = "multi-GPU: the communication callback failed";
+      return SCILMM_ERR_DEVICE;
+    }
+    HIPCHK(hipEventRecord(D->ev_x1, D->comm));
+    HIPCHK(hipStreamWaitEvent(st, D->ev_x1, 0));
+    hipLaunchKernelGGL(k_status_unpack, dim3(1), dim3(1), 0, st, (const double*)(fac->logd + S.nsuper), fac->status);
+  }
   HIPCHK(hipEventRecord(D->ev[2], st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(fac->h_status, fac->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -2077,9 +1991,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   HIPCHK(hipStreamSynchronize(D->side));
   HIPCHK(hipStreamSynchronize(D->side2));
   if (D->side3) HIPCHK(hipStreamSynchronize(D->side3));
-  HIPCHK(hipStreamSynchronize(D->rest));
-  for (auto& cs : D->cside)
-    if (cs) HIPCHK(hipStreamSynchronize(cs));
+  if (D->bstream) HIPCHK(hipStreamSynchronize(D->bstream));
   if (D->world > 1 && D->comm) HIPCHK(hipStreamSynchronize(D->comm));
   if (D->outside_st) HIPCHK(hipStreamSynchronize(D->outside_st));
   float a = 0, f = 0;
@@ -2230,6 +2142,114 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     const size_t sm_fwd = sizeof(double) * (size_t)(NB * LDW + KCS * LDA);
     const int64_t tot = (int64_t)S.n * rp;
     const unsigned pb = (unsigned)((tot + 255) / 256);
+    if (D->world > 1) {
+      // ---- distributed factor.  The prelude is replicated: every rank sweeps it alike.  A tail panel lives on its owner:
+      //   forward : the owner pushes x_f through its panel into ACC (its private sum of tail contributions); when block f
+      //             is due, the ranks ALL-REDUCE the 128 rows of ACC that belong to it, add them to W (which carries the
+      //             right-hand side and the prelude's contributions, identical everywhere) and every rank solves the block
+      //             with the replicated inverse diagonal block: x_f is known everywhere without a broadcast;
+      //   backward: the owner of panel f has received every push into X[f] (a push (target t, descendant f) needs the
+      //             panel of f): it solves the block and BROADCASTS x_f; then every rank pushes x_f into the descendants
+      //             it holds (the prelude: all ranks; tail panels: their owners).
+      //   L * R   : every panel is multiplied where it lives (the prelude on rank 0), one all-reduce of the product.
+      // One collective per tail block and direction, issued on the communication stream between two event hand-offs.
+      const int64_t nW = (int64_t)S.n * RPMAX;  // W | X | ACC inside the caller's work buffer (scilmm_dist_set_work)
+      auto handoff = [&](int32_t op, int64_t off, int64_t cnt, int32_t root) -> int {
+        HIPCHK(hipEventRecord(D->ev_x0, st));
+        HIPCHK(hipStreamWaitEvent(D->comm, D->ev_x0, 0));
+        if (sym->comm_fn(sym->comm_ctx, op, 3, off, cnt, root) != 0) {
+          sym->err = "multi-GPU: the communication callback failed";
+          return SCILMM_ERR_DEVICE;
+        }
+        HIPCHK(hipEventRecord(D->ev_x1, D->comm));
+        HIPCHK(hipStreamWaitEvent(st, D->ev_x1, 0));
+        return SCILMM_OK;
+      };
+      int rcx;
+      if (mode == 1) {
+        hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, (const int32_t*)nullptr, dB, D->W);
+        HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, st));
+        if (D->n_lmul_tiles > 0) {
+          if (mf)
+            hipLaunchKernelGGL((k_fwd<true, 1, true>), dim3((unsigned)D->n_lmul_tiles, gy), dim3(256), sm_fwd, st, D->v, D->d_lmul_tiles,
+                               fac->L, (const double*)D->W, D->X, rp);
+          else
+            hipLaunchKernelGGL((k_fwd<false, 1, true>), dim3((unsigned)D->n_lmul_tiles, gy), dim3(256), sm_fwd, st, D->v, D->d_lmul_tiles,
+                               fac->L, (const double*)D->W, D->X, rp);
+        }
+        if ((rcx = handoff(1, nW, tot, 0)) != SCILMM_OK) return rcx;
+        hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
+        continue;
+      }
+      hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dB, D->W);
+      HIPCHK(hipMemsetAsync(D->ACC, 0, sizeof(double) * (size_t)tot, st));
+      for (int32_t l = 0; l < S.nlevels; ++l) {
+        const int32_t tf = D->tail_of_level[l];
+        const int64_t t0 = D->lv_tile_ptr[l], tm = D->lv_tile_mid[l], t1 = D->lv_tile_ptr[l + 1];
+        const int32_t f0 = S.level_ptr[l], f1 = S.level_ptr[l + 1];  // ALL fronts of the level (replicated diagonal solves)
+        if (f1 == f0) continue;
+        if (tf >= 0) {
+          const int64_t c0 = S.sn_start[tf], wf = S.sn_start[tf + 1] - c0;
+          if ((rcx = handoff(1, 2 * nW + c0 * rp, wf * rp, 0)) != SCILMM_OK) return rcx;
+          hipLaunchKernelGGL(k_add_rows, dim3((unsigned)((wf * rp + 255) / 256)), dim3(256), 0, st, wf * rp, (const double*)(D->ACC + c0 * rp),
+                             D->W + c0 * rp);
+        }
+        if (mf)
+          hipLaunchKernelGGL((k_diag_solve<true, false>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v, D->d_all_fronts + f0,
+                             fac->invD, (const double*)D->W, D->X, rp);
+        else
+          hipLaunchKernelGGL((k_diag_solve<false, false>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v, D->d_all_fronts + f0,
+                             fac->invD, (const double*)D->W, D->X, rp);
+        // pushes of the prelude fronts of the level go to W (atomic: they may share rows), of an own tail panel to ACC
+        if (tm > t0) {
+          if (mf)
+            hipLaunchKernelGGL((k_fwd<true, 0, true>), dim3((unsigned)(tm - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                               fac->L, (const double*)D->X, D->W, rp);
+          else
+            hipLaunchKernelGGL((k_fwd<false, 0, true>), dim3((unsigned)(tm - t0), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + t0,
+                               fac->L, (const double*)D->X, D->W, rp);
+        }
+        if (t1 > tm) {
+          if (mf)
+            hipLaunchKernelGGL((k_fwd<true, 0, false>), dim3((unsigned)(t1 - tm), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + tm,
+                               fac->L, (const double*)D->X, D->ACC, rp);
+          else
+            hipLaunchKernelGGL((k_fwd<false, 0, false>), dim3((unsigned)(t1 - tm), gy), dim3(256), sm_fwd, st, D->v, D->d_level_tiles + tm,
+                               fac->L, (const double*)D->X, D->ACC, rp);
+        }
+      }
+      if (!mid_recorded) {
+        HIPCHK(hipEventRecord(D->ev[4], st));
+        mid_recorded = true;
+      }
+      for (int32_t l = S.nlevels - 1; l >= 0; --l) {
+        const int32_t tf = D->tail_of_level[l];
+        const int32_t f0 = D->lv_ptr[l], f1 = D->lv_ptr[l + 1];  // the fronts this rank holds
+        const int64_t p0 = D->lv_pair_ptr[l], p1 = D->lv_pair_ptr[l + 1];
+        if (f1 > f0) {
+          if (mf)
+            hipLaunchKernelGGL((k_diag_solve<true, true>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v, D->d_level_fronts + f0,
+                               fac->invD, (const double*)D->X, D->X, rp);
+          else
+            hipLaunchKernelGGL((k_diag_solve<false, true>), dim3((unsigned)(f1 - f0), gy), dim3(256), 0, st, D->v, D->d_level_fronts + f0,
+                               fac->invD, (const double*)D->X, D->X, rp);
+        }
+        if (tf >= 0) {
+          const int64_t c0 = S.sn_start[tf], wf = S.sn_start[tf + 1] - c0;
+          if ((rcx = handoff(0, nW + c0 * rp, wf * rp, (tf - D->dist_first) % D->world)) != SCILMM_OK) return rcx;
+        }
+        if (p1 > p0) {
+          if (mf)
+            hipLaunchKernelGGL(k_bwd_push<true>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
+                               (const int64_t*)nullptr, fac->L, D->X, rp, (const int32_t*)nullptr, (double*)nullptr);
+          else
+            hipLaunchKernelGGL(k_bwd_push<false>, dim3((unsigned)(p1 - p0), gy), dim3(256), 0, st, D->v, D->d_level_pairs + p0,
+                               (const int64_t*)nullptr, fac->L, D->X, rp, (const int32_t*)nullptr, (double*)nullptr);
+        }
+      }
+      hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, D->X, dX);
+      continue;
+    }
     if (mode == 0) {
       hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, st, S.n, r, rp, cbeg, D->v.perm, dB, D->W);
       const int32_t lend = D->chain_T > 0 ? D->chain_l0 : S.nlevels;  // the chain levels are swept by k_chain
@@ -2452,22 +2472,71 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) 
 
 // slack behind L and invD: the chain sweeps read whole 4-deep k-steps of a panel / an inverse block and discard the
 // lanes past its last column (at most 3 columns of the tallest panel resp. of an NB-wide block)
-static void factor_sizes(const Symbolic& S, size_t* nL, size_t* padL, size_t* nI, size_t* padI) {
+static void factor_sizes(const scilmm_symbolic* sym, size_t* nL, size_t* padL, size_t* nI, size_t* padI) {
+  const Symbolic& S = *sym->S;
   int64_t max_m = 0;
   for (int32_t q = 0; q < S.nsuper; ++q) max_m = std::max<int64_t>(max_m, S.sn_rowptr[q + 1] - S.sn_rowptr[q]);
   *padL = (size_t)(4 * max_m + 4 * NB);
   *padI = (size_t)(5 * NB);
   *nL = (size_t)std::max<int64_t>(S.nnzL_stored, 1);
+  if (sym->world > 1) {  // rank-local storage: prelude + own tail panels + ring (DistLayout)
+    DistLayout lay;
+    dist_layout(S, sym->rank, sym->world, &lay);
+    *nL = (size_t)std::max<int64_t>(lay.nL, 1);
+  }
   *nI = (size_t)std::max<int64_t>(S.inv_off[S.nsuper], 1);
 }
 
 int scilmm_factor_sizes(const scilmm_symbolic* sym, int64_t* L_doubles, int64_t* invD_doubles, int64_t* logd_doubles) {
   if (!sym || !sym->S) return SCILMM_ERR_ARG;
   size_t nL, padL, nI, padI;
-  factor_sizes(*sym->S, &nL, &padL, &nI, &padI);
+  factor_sizes(sym, &nL, &padL, &nI, &padI);
   if (L_doubles) *L_doubles = (int64_t)(nL + padL);
   if (invD_doubles) *invD_doubles = (int64_t)(nI + padI);
-  if (logd_doubles) *logd_doubles = (int64_t)std::max(sym->S->nsuper, 1);
+  if (logd_doubles) *logd_doubles = (int64_t)sym->S->nsuper + 1;  // + one slot for the status word's trip through the comm layer
+  return SCILMM_OK;
+}
+
+int scilmm_dist_layout(const scilmm_symbolic* sym, int32_t rank, int32_t world, int32_t* owner, int64_t* loff, int32_t* params) {
+  if (!sym || !sym->S || world < 1 || rank < 0 || rank >= world) return SCILMM_ERR_ARG;
+  const Symbolic& S = *sym->S;
+  DistLayout lay;
+  dist_layout(S, rank, world, &lay);
+  if (owner)
+    for (int32_t f = 0; f < S.nsuper; ++f) owner[f] = (world > 1 && f >= lay.first) ? (f - lay.first) % world : -1;
+  if (loff) {
+    std::memcpy(loff, lay.loff.data(), sizeof(int64_t) * (size_t)S.nsuper);
+    loff[S.nsuper] = lay.nL;
+  }
+  if (params) {
+    params[0] = lay.first;
+    params[1] = lay.Wg;
+    params[2] = lay.G;
+  }
+  return SCILMM_OK;
+}
+
+int scilmm_dist_work_size(const scilmm_symbolic* sym, int64_t* doubles) {
+  if (!sym || !sym->S || !doubles) return SCILMM_ERR_ARG;
+  *doubles = (int64_t)3 * std::max(sym->S->n, 1) * RPMAX;
+  return SCILMM_OK;
+}
+
+int scilmm_dist_set_work(scilmm_symbolic* sym, double* work) {
+  if (!sym || !sym->S || !work) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  if ((D->W || D->X) && !D->work_external) {
+    sym->err = "scilmm_dist_set_work must precede the first solve on this handle";
+    return SCILMM_ERR_STATE;
+  }
+  const size_t nW = (size_t)std::max(sym->S->n, 1) * RPMAX;
+  D->W = work;
+  D->X = work + nW;
+  D->ACC = work + 2 * nW;
+  D->work_external = true;
   return SCILMM_OK;
 }
 
@@ -2481,7 +2550,7 @@ static int factor_create(scilmm_symbolic* sym, double* L_ext, double* invD_ext, 
   f->device = D->device;
   *out = f;
   size_t nL, padL, nI, padI;
-  factor_sizes(S, &nL, &padL, &nI, &padI);
+  factor_sizes(sym, &nL, &padL, &nI, &padI);
   if (L_ext) {
     f->external = true;
     f->L = L_ext;
@@ -2490,7 +2559,7 @@ static int factor_create(scilmm_symbolic* sym, double* L_ext, double* invD_ext, 
   } else {
     HIPCHK(hipMalloc((void**)&f->L, sizeof(double) * (nL + padL)));
     HIPCHK(hipMalloc((void**)&f->invD, sizeof(double) * (nI + padI)));
-    HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * (size_t)std::max(S.nsuper, 1)));
+    HIPCHK(hipMalloc((void**)&f->logd, sizeof(double) * ((size_t)S.nsuper + 1)));
   }
   HIPCHK(hipMemset(f->L + nL, 0, sizeof(double) * padL));
   // (all of invD: k_potrf only ever writes the lower triangles, the upper ones must read as zero)
@@ -2734,6 +2803,10 @@ int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double
   }
   if (!fac->valid) return SCILMM_ERR_STATE;
   Dev* D = (Dev*)sym->device;
+  if (D->world > 1) {
+    sym->err = "Factor.L(): a distributed factor is not gathered (every rank holds its own tail panels only)";
+    return SCILMM_ERR_STATE;
+  }
   std::vector<double> h((size_t)std::max<int64_t>(S.nnzL_stored, 1));
   HIPCHK(hipMemcpyAsync(h.data(), fac->L, sizeof(double) * (size_t)S.nnzL_stored, hipMemcpyDeviceToHost, D->stream));
   HIPCHK(hipStreamSynchronize(D->stream));

@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
-#include "../kernels.hip.h"
+#include "retired_kernels.hip.h"
 using namespace scilmm;
 
 // operands: 0 = zeros (read HIGH: zero MFMA operands raise the clock), 1 = full-range uniform [-1, 1)

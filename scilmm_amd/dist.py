@@ -2,26 +2,28 @@
 (backend "nccl" = RCCL over xGMI; "gloo" in the CPU / one-GPU rehearsals).
 
 What is distributed, and why this way.  A pedigree factor is a sparse prelude (hundreds of thousands of small
-fronts) below a chain of separator supernodes that ends in the dense trailing clique: 76 % of the factor flops at
-the 100k config, > 99.9 % at the 1M config (170k-wide clique, 1.6 PFLOP) -- ``profiles/r2_ordering.json`` shows that
-neither minimum degree nor nested dissection finds a smaller top separator.  Independent subtrees therefore carry
-(almost) none of the work; the separator chain itself has to be shared:
+fronts) below the dense tail: the separator supernodes that end in the trailing clique -- 76 % of the factor flops at
+the 100k config, > 99.9 % at the 1M config (178k columns, 1.6 PFLOP, 123 GB) -- and ``profiles/r2_ordering.json`` shows
+that neither minimum degree nor nested dissection finds a smaller top separator.  Independent subtrees carry (almost)
+none of the work, and the tail alone outgrows one GPU's memory at BASELINE configs[4] (3M individuals: ~1.3 TB).  So:
 
-* **chain panels, 1-D block-cyclic.**  The trailing run of single-front levels of the block elimination tree is the
-  distributed chain.  Rank r computes chain panel j iff ``j % world == r`` -- left-looking: all the update
-  contributions (the extend-add of every descendant, prelude and chain alike) are summed where the panel lives --
-  then the finished panel, its inverse diagonal block and its log-sum are **broadcast** to all ranks.  A rank
-  applies the contributions of everything older than its previous own panel ahead of time (look-ahead depth =
-  world), so only the last ``world`` source panels sit on the critical path.
-* **the prelude is replicated** (every rank factors it; < 0.1 % of the flops at 1M).  Its contribution blocks are
-  consumed locally by whoever owns the target chain panel: no reduce is needed for them.
-* **after the factorization every rank holds the complete factor**, so the solves need no sweep across GPUs:
-  the right-hand-side COLUMNS are split over the ranks (103 columns per REML evaluation) and all-gathered.
+* **tail panels, 1-D block-cyclic, FAN-OUT, rank-local storage.**  Tail front ``dense_first + j`` belongs to rank
+  ``j % world``.  A rank stores the prelude, its own tail panels and a ring of a few panel slots.  A finished panel is
+  **broadcast** by its owner into the receivers' ring; every rank applies it to its own later targets and drops it:
+  per rank ``nnz(L_tail) / world`` + ring instead of the whole factor.  To keep the accumulators of the update kernel
+  in registers over a deep K, sources are applied a GROUP (8 panels) at a time: when group g is complete, one batch
+  launch updates every own target at least two groups ahead; the sources of a target's own group and of the one
+  before it are its "late" update, right before its diagonal block is factored.
+* **the prelude is replicated** (every rank factors it; < 0.1 % of the flops at 1M).
+* **the triangular sweeps** run where the panels are: forward, the owner pushes x_f through its panel into a private
+  accumulator and the ranks all-reduce the 128 rows of a block when it is due (the inverse diagonal blocks are
+  replicated, so every rank then solves the block itself); backward, the owner solves its block and broadcasts x_f;
+  L*R is multiplied panel by panel where the panels live and summed by one all-reduce.  Every rank ends with the full
+  result, like the single-GPU calls.
 
-The communication pattern (broadcast of panel j from ``j % world``, in chain order; all-gather of solution
-columns) lives here, in Python, on top of ``torch.distributed``; the HIP engine only orders its streams around the
-callbacks (``scilmm_dist_init``).  The same evaluator drives a CPU engine in ``tests/test_distributed_cpu.py``
-(world_size 2, gloo) so that the N > 1 logic is covered without a GPU.
+The communication pattern lives here, in Python, on top of ``torch.distributed``; the HIP engine only orders its
+streams around the callbacks (``scilmm_dist_init``).  The same evaluator drives a CPU engine with the same rule in
+``tests/test_distributed_cpu.py`` (world_size 2 / 4 / 8, gloo) so that the N > 1 logic is covered without a GPU.
 """
 import ctypes as C
 
@@ -29,15 +31,6 @@ import numpy as np
 import scipy.linalg as la
 
 from . import _lib
-
-
-def chain_levels(level_ptr):
-    """First level of the distributed chain: the trailing run of levels that hold exactly one front."""
-    nlev = len(level_ptr) - 1
-    l0 = nlev
-    while l0 > 0 and level_ptr[l0] - level_ptr[l0 - 1] == 1:
-        l0 -= 1
-    return l0
 
 
 def column_chunks(r, world):
@@ -51,46 +44,22 @@ def column_chunks(r, world):
     return out
 
 
-class ColumnSplit(object):
-    """Runs a column-wise linear map (solve, L*R, quadratic forms) on this rank's share of the columns and
-    all-gathers the result, so that every rank ends with the full array."""
-
-    def __init__(self, rank, world, dist=None, device=None):
-        self.rank, self.world, self.dist, self.device = rank, world, dist, device
-
-    def _gather(self, local, shapes):
-        if self.world == 1 or self.dist is None:
-            return [local]
-        import torch
-        dev = self.device if self.device is not None else "cpu"
-        width = max(s[1] - s[0] for s in shapes)
-        pad = np.zeros(local.shape[:-1] + (width,))
-        pad[..., :local.shape[-1]] = local
-        mine = torch.from_numpy(np.ascontiguousarray(pad)).to(dev)
-        parts = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(parts, mine)
-        return [p.cpu().numpy()[..., :s[1] - s[0]] for p, s in zip(parts, shapes)]
-
-    def apply(self, fn, B):
-        """fn maps an (n, k) block to an (n, k) block column by column; B is (n, r)."""
-        B = np.asarray(B, dtype=np.float64)
-        chunks = column_chunks(B.shape[1], self.world)
-        c0, c1 = chunks[self.rank]
-        local = fn(np.ascontiguousarray(B[:, c0:c1])) if c1 > c0 else np.zeros((B.shape[0], 0))
-        return np.concatenate(self._gather(local, chunks), axis=1)
-
-    def apply_reduce(self, fn, B):
-        """fn maps an (n, k) block to k numbers (one per column)."""
-        B = np.asarray(B, dtype=np.float64)
-        chunks = column_chunks(B.shape[1], self.world)
-        c0, c1 = chunks[self.rank]
-        local = np.asarray(fn(np.ascontiguousarray(B[:, c0:c1])), dtype=np.float64) if c1 > c0 else np.zeros(0)
-        return np.concatenate(self._gather(local, chunks))
+def tail_layout(sym_handle, nsuper, rank, world):
+    """The distribution rule as data, straight from the library (``scilmm_dist_layout``): owner per front (-1 =
+    replicated), rank-local panel offsets (last entry: doubles of local panel storage), (first distributed front,
+    group size, ring slots).  Host only."""
+    owner = np.empty(nsuper, dtype=np.int32)
+    loff = np.empty(nsuper + 1, dtype=np.int64)
+    params = np.empty(3, dtype=np.int32)
+    _lib.check(_lib.lib().scilmm_dist_layout(sym_handle, rank, world, _lib.ptr(owner), _lib.ptr(loff), _lib.ptr(params)), sym_handle)
+    return owner, loff, (int(params[0]), int(params[1]), int(params[2]))
 
 
 class HipChainEngine(object):
-    """The HIP engine as one rank of a distributed factorization: torch-owned factor storage, broadcasts issued by
-    the engine's callback on a dedicated torch stream."""
+    """The HIP engine as one rank of a distributed factorization: torch-owned storage (this rank's share of the factor,
+    the sweeps' work buffer), collectives issued by the engine's callback on a dedicated torch stream."""
+
+    device_resident = True
 
     def __init__(self, mats, rank, world, dist, device, perm=None, ordering="amd"):
         import torch
@@ -99,8 +68,9 @@ class HipChainEngine(object):
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self._comm_stream = torch.cuda.Stream(device=self.device)
-        self._bufs = [None, None, None]
+        self._bufs = [None, None, None, None]
         self._cb_error = None
+        self.collectives = 0
 
         def _comm(ctx, op, buffer, offset, count, root):
             try:
@@ -108,8 +78,11 @@ class HipChainEngine(object):
                 with torch.cuda.stream(self._comm_stream):
                     if op == 0:
                         dist.broadcast(t, src=root)
-                    else:
+                    elif op == 1:
                         dist.all_reduce(t)
+                    else:
+                        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                self.collectives += 1
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 self._cb_error = e
@@ -117,31 +90,40 @@ class HipChainEngine(object):
 
         self._cb = _lib.COMM_FN(_comm)  # keep the callback object alive as long as the engine
         self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False)
-        _lib.check(_lib.lib().scilmm_dist_init(self.sym._h, rank, world, C.c_void_p(self._comm_stream.cuda_stream),
-                                               self._cb, None), self.sym._h)
+        L = _lib.lib()
+        _lib.check(L.scilmm_dist_init(self.sym._h, rank, world, C.c_void_p(self._comm_stream.cuda_stream), self._cb, None), self.sym._h)
         self.sym.upload_values()
-        nL, nI, nS = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        _lib.check(_lib.lib().scilmm_factor_sizes(self.sym._h, C.byref(nL), C.byref(nI), C.byref(nS)), self.sym._h)
+        nL, nI, nS, nW = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.check(L.scilmm_factor_sizes(self.sym._h, C.byref(nL), C.byref(nI), C.byref(nS)), self.sym._h)
+        _lib.check(L.scilmm_dist_work_size(self.sym._h, C.byref(nW)), self.sym._h)
+        self.local_factor_doubles = nL.value
         self._bufs = [torch.empty(nL.value, dtype=torch.float64, device=self.device),
                       torch.empty(nI.value, dtype=torch.float64, device=self.device),
-                      torch.zeros(nS.value, dtype=torch.float64, device=self.device)]
+                      torch.zeros(nS.value, dtype=torch.float64, device=self.device),
+                      torch.zeros(nW.value, dtype=torch.float64, device=self.device)]
         torch.cuda.synchronize(self.device)
+        _lib.check(L.scilmm_dist_set_work(self.sym._h, C.c_void_p(self._bufs[3].data_ptr())), self.sym._h)
         h = C.c_void_p()
-        _lib.check(_lib.lib().scilmm_factor_create_external(self.sym._h, C.c_void_p(self._bufs[0].data_ptr()),
-                                                            C.c_void_p(self._bufs[1].data_ptr()),
-                                                            C.c_void_p(self._bufs[2].data_ptr()), C.byref(h)), self.sym._h)
+        _lib.check(L.scilmm_factor_create_external(self.sym._h, C.c_void_p(self._bufs[0].data_ptr()),
+                                                   C.c_void_p(self._bufs[1].data_ptr()),
+                                                   C.c_void_p(self._bufs[2].data_ptr()), C.byref(h)), self.sym._h)
         from .factor import Factor
         self.fac = Factor.__new__(Factor)
         self.fac.sym, self.fac.n, self.fac._h, self.fac._s2 = self.sym, self.sym.n, h, None
         self.n = self.sym.n
 
-    def factorize(self, sigma2):
+    def _guard(self, fn, *a):
         try:
-            self.fac.refactorize(sigma2)
+            return fn(*a)
         except Exception:
             if self._cb_error is not None:
-                raise self._cb_error
+                err, self._cb_error = self._cb_error, None
+                raise err
             raise
+
+    def factorize(self, sigma2):
+        """Every rank raises NotPositiveDefiniteError together (the status word is all-reduced inside the library)."""
+        self._guard(self.fac.refactorize, sigma2)
         return self
 
     def P(self):
@@ -150,25 +132,64 @@ class HipChainEngine(object):
     def logdet(self):
         return self.fac.logdet()
 
-    def solve_local(self, B):
-        return self.fac(B)
+    # host arrays in, host arrays out (every rank gets the full result)
+    def solve(self, B):
+        return self._guard(self.fac, B)
 
-    def lmul_local(self, R):
-        return self.fac.lmul(R)
+    def lmul(self, R):
+        return self._guard(self.fac.lmul, R)
 
-    def quadforms_local(self, k, Q):
+    def quadforms(self, k, Q):
         return self.sym.quadforms(k, Q)
+
+    # device tensors in, device tensors out: the n x 100 blocks of an evaluation never leave HBM
+    def solve_t(self, dB):
+        dX = self.torch.empty_like(dB)
+        self.torch.cuda.synchronize(self.device)
+        self._guard(self.fac.solve_dev, C.c_void_p(dB.data_ptr()), dB.shape[1], C.c_void_p(dX.data_ptr()))
+        self._guard(self.sym.sync)
+        return dX
+
+    def lmul_t(self, dR):
+        dZ = self.torch.empty_like(dR)
+        self.torch.cuda.synchronize(self.device)
+        self._guard(self.fac.lmul_dev, C.c_void_p(dR.data_ptr()), dR.shape[1], C.c_void_p(dZ.data_ptr()))
+        self._guard(self.sym.sync)
+        return dZ
+
+    def quadforms_t(self, k, dQ):
+        dq = self.torch.empty(dQ.shape[1], dtype=self.torch.float64, device=self.device)
+        self.torch.cuda.synchronize(self.device)
+        self.sym.quadforms_dev(k, C.c_void_p(dQ.data_ptr()), dQ.shape[1], C.c_void_p(dq.data_ptr()))
+        self.sym.sync()
+        return dq
 
 
 class DistributedEvaluator(object):
     """One REML likelihood + gradient evaluation (fused form of reference SparseCholesky.py:77-117) with the factor
-    distributed over the ranks of ``dist``.  ``engine``: ``HipChainEngine`` on GPUs, a CPU stand-in in the tests.
-    Every rank returns the same (nll, grad): the column results are all-gathered, the scalars are computed
-    redundantly from them."""
+    distributed over the ranks of ``dist``.  ``engine``: ``HipChainEngine`` on GPUs (the n x 100 blocks stay in HBM as
+    torch tensors; only c + 1 solution columns and the quadratic forms reach the host), a CPU stand-in in the tests
+    (NumPy arrays).  The factor sweeps are collective (every rank takes part in every column); the quadratic forms --
+    a streaming pass over the replicated A_k values -- are split by COLUMNS over the ranks and all-gathered.
+    Every rank returns the same (nll, grad)."""
 
     def __init__(self, engine, mats, C_cov, y, rank, world, dist=None, device=None):
         self.engine, self.mats, self.C, self.y = engine, mats, np.asarray(C_cov, float), np.asarray(y, float)
-        self.split = ColumnSplit(rank, world, dist, device)
+        self.rank, self.world, self.dist, self.device = rank, world, dist, device
+
+    def _gather_vec(self, local, chunks):
+        """local: this rank's slice of a length-r vector (host array) -> the full vector on every rank."""
+        if self.world == 1 or self.dist is None:
+            return np.asarray(local)
+        import torch
+        width = max(b - a for a, b in chunks)
+        pad = np.zeros(width)
+        pad[:len(local)] = local
+        dev = self.device if self.device is not None else "cpu"
+        mine = torch.from_numpy(pad).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return np.concatenate([p.cpu().numpy()[:b - a] for p, (a, b) in zip(parts, chunks)])
 
     def evaluate(self, log_s2, reml=True, sim_num=100):
         s2 = np.exp(np.asarray(log_s2, dtype=float))
@@ -176,9 +197,19 @@ class DistributedEvaluator(object):
         eng.factorize(s2)
         n, c = self.y.size, self.C.shape[1]
         R = np.random.randn(n, sim_num)  # the same global normal matrix on every rank (SparseCholesky.py:50)
-        Z = self.split.apply(eng.lmul_local, R)
-        X = self.split.apply(eng.solve_local, np.hstack([self.C, self.y[:, None], Z]))
-        ViC, Viy0, U = X[:, :c], X[:, c], X[:, c + 1:]
+        on_dev = getattr(eng, "device_resident", False)
+        if on_dev:
+            torch = eng.torch
+            dZ = eng.lmul_t(torch.from_numpy(R).to(eng.device))
+            head = torch.from_numpy(np.ascontiguousarray(np.hstack([self.C, self.y[:, None]]))).to(eng.device)
+            dX = eng.solve_t(torch.cat([head, dZ], dim=1).contiguous())
+            del dZ
+            Xh = dX[:, :c + 1].cpu().numpy()
+            ViC, Viy0 = Xh[:, :c], Xh[:, c]
+        else:
+            Z = eng.lmul(R)
+            X = eng.solve(np.hstack([self.C, self.y[:, None], Z]))
+            ViC, Viy0, U = X[:, :c], X[:, c], X[:, c + 1:]
         G = la.cho_factor(self.C.T @ ViC)
         beta = la.cho_solve(G, self.C.T @ Viy0)
         Viy = Viy0 - ViC @ beta
@@ -187,15 +218,27 @@ class DistributedEvaluator(object):
         if reml:
             nll += np.log(np.diag(G[0])).sum()
         pairs = [(a, b) for a in range(c) for b in range(a + 1, c)] if reml else []
-        cols = [U, Viy[:, None]]
+        tail = [Viy[:, None]]
         if reml:
-            cols.append(ViC)
-            cols += [(ViC[:, a] + ViC[:, b])[:, None] for a, b in pairs]
-        Q = np.ascontiguousarray(np.hstack(cols))
+            tail.append(ViC)
+            tail += [(ViC[:, a] + ViC[:, b])[:, None] for a, b in pairs]
+        tail = np.ascontiguousarray(np.hstack(tail))
+        rq = sim_num + tail.shape[1]
+        chunks = column_chunks(rq, self.world)
+        q0, q1 = chunks[self.rank]
+        if on_dev:
+            dQ = torch.cat([dX[:, c + 1:], torch.from_numpy(tail).to(eng.device)], dim=1)[:, q0:q1].contiguous()
+            del dX
+        else:
+            Q = np.ascontiguousarray(np.hstack([U, tail])[:, q0:q1])
         K = len(self.mats)
         grad = np.empty(K)
         for k in range(K):
-            q = self.split.apply_reduce(lambda blk, k=k: eng.quadforms_local(k, blk), Q)
+            if q1 > q0:
+                loc = eng.quadforms_t(k, dQ).cpu().numpy() if on_dev else np.asarray(eng.quadforms(k, Q))
+            else:
+                loc = np.zeros(0)
+            q = self._gather_vec(loc, chunks)
             grad[k] = 0.5 * (q[:sim_num].mean() - q[sim_num])
             if reml:
                 Mk = np.zeros((c, c))
