@@ -16,10 +16,12 @@ device plan) is the warm-up, then as many timed steps as fit are run (at least o
 actually run as `steps` / `warmup` and the requested ones as `steps_requested` / `warmup_requested`.  Small
 workloads (--workload 100k) fit the requested counts and run them unchanged.
 
-For N > 1 the N ranks factorize the SAME ONE cohort together (strong scaling, BASELINE configs[3]): the separator
-chain of the block elimination tree -- > 99.9 % of the flops at 1M -- is distributed 1-D block-cyclically, every
-finished chain panel is broadcast from its owner over RCCL/xGMI (scilmm_amd/dist.py), and the 103 right-hand-side
-columns of the solve are split over the ranks and all-gathered.  Rank 0 prints one JSON line.
+For N > 1 the N ranks factorize the SAME ONE cohort together (strong scaling, BASELINE configs[3]): the panels of the
+dense tail of the block elimination tree -- > 99.9 % of the flops and of the storage at 1M -- are owned 1-D
+block-cyclically; a finished panel is broadcast by its owner over RCCL/xGMI into the receivers' ring, applied to
+their own targets and dropped (fan-out, rank-local storage: scilmm_amd/dist.py), and the 103-column solve runs
+collectively (one small all-reduce / broadcast per tail block).  Rank 0 prints one JSON line.  `python bench.py
+--gpus N` starts its N ranks itself; under a launcher (RANK / WORLD_SIZE set) it is one of them.
 """
 import argparse
 import ctypes
@@ -251,7 +253,7 @@ def main():
             sym_opts[k] = float(v) if "z" in k or "relax" == k[:5] and "." in v else int(v)
         sym = Symbolic([A, sp.identity(n, format="csr")], **sym_opts)
     else:
-        from scilmm_amd.dist import HipChainEngine, column_chunks
+        from scilmm_amd.dist import HipChainEngine
         eng = HipChainEngine([A, sp.identity(n, format="csr")], rank, world, dist, dev)
         sym = eng.sym
     t_sym = time.time() - t0
@@ -264,17 +266,8 @@ def main():
     r = c + 1 + s
     rng = np.random.default_rng(100)  # the same right-hand sides on every rank
     B_host = np.hstack([C, y[:, None], rng.standard_normal((n, s))])
-    if world == 1:
-        c0r, c1r, wpad = 0, r, r
-    else:
-        chunks = column_chunks(r, world)
-        c0r, c1r = chunks[rank]
-        wpad = max(b - a for a, b in chunks)  # equal-size all-gather: pad every rank's slice to the widest one
-    B_loc = np.zeros((n, wpad))
-    B_loc[:, :c1r - c0r] = B_host[:, c0r:c1r]
-    dB = torch.from_numpy(B_loc).to(dev)
+    dB = torch.from_numpy(B_host).to(dev)   # every rank takes part in every column of the (collective) sweep
     dX = torch.empty_like(dB)
-    gathered = [torch.empty_like(dX) for _ in range(world)] if world > 1 else None
     torch.cuda.synchronize()
 
     state = {"fac": None}
@@ -293,10 +286,8 @@ def main():
             state["fac"].refactorize(sigma2_of(i))
         fac = state["fac"]
         logdets.append(fac.logdet())
-        fac.solve_dev(ctypes.c_void_p(dB.data_ptr()), wpad, ctypes.c_void_p(dX.data_ptr()))
-        sym.sync()
-        if world > 1:
-            dist.all_gather(gathered, dX)  # every rank ends with all 103 solution columns (as the REML evaluation needs)
+        fac.solve_dev(ctypes.c_void_p(dB.data_ptr()), r, ctypes.c_void_p(dX.data_ptr()))
+        sym.sync()  # (N > 1: every rank ends with all 103 solution columns, as the REML evaluation needs)
 
     t0 = time.time()
     step(0)  # the plan-building evaluation always runs before the timed region: it is the first warm-up step
@@ -338,10 +329,7 @@ def main():
 
     # residual check of the last solve (outside the timed region)
     fac = state["fac"]
-    if world == 1:
-        X = dX[:, :r].cpu().numpy()
-    else:
-        X = np.concatenate([g.cpu().numpy()[:, :b - a] for g, (a, b) in zip(gathered, chunks)], axis=1)
+    X = dX[:, :r].cpu().numpy()
     s2 = sigma2_of(steps - 1)
     probe = [0, c, r - 1]  # first covariate column, the phenotype, the last simulated vector (last rank's share)
     resid = float(np.abs(s2[0] * (A @ X[:, probe]) + s2[1] * X[:, probe] - B_host[:, probe]).max() / np.abs(B_host[:, probe]).max())
@@ -396,8 +384,10 @@ def main():
                        "n": n, "nnz_tril_A": int((A.nnz + n) // 2), "nnzL": int(info.nnzL),
                        "nnzL_stored": int(info.nnzL_stored), "factor_flops": info.flops, "nsuper": info.nsuper,
                        "nlevels": info.nlevels,
-                       "parallelism": "1 GPU" if world == 1 else "one cohort over %d ranks: separator chain 1-D block-cyclic "
-                                      "with panel broadcast (RCCL), prelude replicated, solve columns split" % world,
+                       "parallelism": "1 GPU" if world == 1 else "one cohort over %d ranks: dense-tail panels 1-D block-cyclic, fan-out "
+                                      "with rank-local storage (panel broadcast over RCCL into a ring, batched group updates), "
+                                      "prelude replicated, collective sweeps" % world,
+                       "local_factor_GB": (8e-9 * eng.local_factor_doubles) if eng is not None else 8e-9 * info.nnzL_stored,
                        "seconds_per_step": elapsed / K,
                        "factorize_ms": prof["factor_ms"] / K, "assemble_ms": prof["assemble_ms"] / K,
                        "solve_ms": (prof["solve_fwd_ms"] + prof["solve_bwd_ms"]) / K,

@@ -25,6 +25,13 @@ def parents_of(rel):
 
 def dominance(rel, ibd):
     from .. import _lib
+    ibd = ibd.tocsr()
     D = _lib.dominance(ibd, parents_of(rel))
     D.eliminate_zeros()  # like the reference's closing sparse arithmetic (Dominance.py:41-43): zeros are not stored
+    if D.shape[0] > 0 and not np.all(D.diagonal() == 1.0):
+        # the device kernel writes the unit diagonal where the IBD pattern STORES one (always, for a relationship matrix);
+        # the reference sets D_ii = 1 for every i whatever ibd holds there (Dominance.py:41-42)
+        D = D.tolil()
+        D.setdiag(1.0)
+        D = D.tocsr()
     return D

@@ -79,7 +79,7 @@ void amd_order(int32_t n, const int64_t* g_ptr, const int32_t* g_idx, int32_t* p
   a.order_pos.assign(n, -1);
   a.w.assign(n, 1);
   a.is_elem.assign(n, 0);
-  std::memcpy(a.iw.data(), g_idx, sizeof(int32_t) * nz);
+  if (nz > 0) std::memcpy(a.iw.data(), g_idx, sizeof(int32_t) * nz);  // (an edgeless graph hands over a null g_idx)
   a.pfree = nz;
 
   int32_t dense = (dense_factor <= 0) ? n : (int32_t)std::max(16.0, dense_factor * std::sqrt((double)n));

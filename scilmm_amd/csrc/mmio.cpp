@@ -66,8 +66,10 @@ inline const char* parse_line(const char* p, const char* e, bool pattern, Entry*
     p = r3.ptr;
   }
   while (p < e && *p != '\n') ++p;
-  out->i = (int32_t)(i - 1);
-  out->j = (int32_t)(j - 1);
+  // range-check BEFORE narrowing: an index such as 4294967297 must not wrap into a valid one (the caller compares the
+  // int32 fields with the header's dimensions; -1 fails that test for every dimension)
+  out->i = (i >= 1 && i <= (long long)INT32_MAX) ? (int32_t)(i - 1) : -1;
+  out->j = (j >= 1 && j <= (long long)INT32_MAX) ? (int32_t)(j - 1) : -1;
   out->v = v;
   return p < e ? p + 1 : e;
 }

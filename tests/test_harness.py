@@ -110,6 +110,11 @@ def test_native_matrix_market_reader_matches_scipy(tmp_path):
     bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")
     with pytest.raises(_lib.ScilmmError):
         _lib.read_matrix_market(str(bad))
+    # an index beyond int32 must not wrap into a valid one (4294967297 = 2^32 + 1 would read as row 1): ADVICE r2
+    for line in ("4294967297 1 1.0", "1 4294967298 1.0", "0 1 1.0", "-1 1 1.0", "3 1 1.0"):
+        bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n" + line + "\n")
+        with pytest.raises(_lib.ScilmmError):
+            _lib.read_matrix_market(str(bad))
 
 
 def test_quick_id_sees_in_place_edits():

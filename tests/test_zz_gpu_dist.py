@@ -1,8 +1,8 @@
-"""Multi-rank path of the HIP engine, rehearsed on ONE GPU: two processes share the card and exchange the chain
-panels through torch.distributed/gloo (RCCL refuses two ranks on one device; the engine only sees a callback, so
-the code path -- ownership filter of the plan, event ordering around the broadcasts, replicated factor, column-split
-solves -- is the one that runs with backend "nccl" on a multi-GPU node).  The file name sorts last on purpose: a
-failure here must not take the single-GPU parity tests with it."""
+"""Multi-rank path of the HIP engine, rehearsed on ONE GPU: two or three processes share the card and exchange the tail
+panels through torch.distributed/gloo (RCCL refuses two ranks on one device; the engine only sees a callback, so the
+code path -- ownership filter of the plan, rank-local panel storage with the ring, the batches, event ordering around
+the collectives, collective sweeps -- is the one that runs with backend "nccl" on a multi-GPU node).  The file name
+sorts last on purpose: a failure here must not take the single-GPU parity tests with it."""
 import os
 import socket
 
@@ -24,7 +24,7 @@ def _free_port():
 
 
 def _problem():
-    A, sex = small_pedigree(20000, 0.01, 3)
+    A, sex = small_pedigree(20000, 0.01, 1)   # 24 tail panels
     n = A.shape[0]
     rng = np.random.default_rng(2)
     y = rng.standard_normal(n)
@@ -34,13 +34,13 @@ def _problem():
 
 def _worker(rank, world, port, out, env):
     import faulthandler
-    faulthandler.dump_traceback_later(240, exit=True)  # a stuck collective must not leave a process on the GPU
+    faulthandler.dump_traceback_later(300, exit=True)  # a stuck collective must not leave a process on the GPU
     os.environ.update(env)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from scilmm_amd.dist import DistributedEvaluator, HipChainEngine
+    from scilmm_amd.dist import DistributedEvaluator, HipChainEngine, tail_layout
     mats, C, y = _problem()
     eng = HipChainEngine(mats, rank, world, dist, "cuda:0")
     ev = DistributedEvaluator(eng, mats, C, y, rank, world, dist, device="cpu")
@@ -49,28 +49,31 @@ def _worker(rank, world, port, out, env):
     ld1 = eng.logdet()
     rng = np.random.default_rng(0)
     B = rng.standard_normal((y.size, 7))
-    X1 = eng.solve_local(B)
+    X1 = eng.solve(B)
     eng.factorize([0.3, 0.7])  # a second factorization on the same handle (stale panels must not survive)
-    np.savez(out % rank, nll=nll, grad=grad, logdet=ld1, X=X1, logdet2=eng.logdet(), X2=eng.solve_local(B),
-             Z2=eng.lmul_local(B), perm=eng.P())
+    info = eng.sym.info()
+    _, loff, params = tail_layout(eng.sym._h, info.nsuper, rank, world)
+    np.savez(out % rank, nll=nll, grad=grad, logdet=ld1, X=X1, logdet2=eng.logdet(), X2=eng.solve(B), Z2=eng.lmul(B),
+             perm=eng.P(), local=loff[-1], total=info.nnzL_stored, params=np.array(params), nsuper=info.nsuper)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("env", [{}, {"SCILMM_TUNING": "1", "SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1"}],
-                         ids=["default", "dense+outside"])
-def test_two_ranks_one_gpu_match_single_process(tmp_path, env):
-    """env 2 forces, at this small size, the schedule the 300k / 1M configurations get by default on every rank of a
-    multi-GPU run: dense-tail kernel + atomic prelude -> tail contributions, restricted to the panels a rank owns."""
+@pytest.mark.parametrize("world,env", [(2, {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "2"}), (2, {}),
+                                       (3, {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "3", "SCILMM_OUTSIDE": "1"})],
+                         ids=["2 ranks, groups of 2 (ring re-used)", "2 ranks, default rule", "3 ranks, groups of 3, k_outside"])
+def test_ranks_sharing_one_gpu_match_single_process(tmp_path, world, env):
+    """24 tail panels over 2 / 3 ranks.  Groups of 2: ring of 8 slots, re-used three times, 12 batches; default: groups of
+    8.  The third case also forces the atomic prelude -> tail contributions (k_outside, the 300k / 1M default) restricted
+    to the panels a rank owns."""
     import torch.multiprocessing as mp
     from oracle import reml_oracle as RO
     from scilmm_amd.factor import Symbolic
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out, env), nprocs=2, join=True)
-    got = [np.load(out % r) for r in range(2)]
+    mp.spawn(_worker, args=(world, _free_port(), out, env), nprocs=world, join=True)
+    got = [np.load(out % r) for r in range(world)]
     mats, C, y = _problem()
     sym = Symbolic(mats)
-    assert np.array_equal(got[0]["perm"], sym.P()) and np.array_equal(got[1]["perm"], sym.P())
     f = sym.factorize([0.45, 0.5])
     rng = np.random.default_rng(0)
     B = rng.standard_normal((y.size, 7))
@@ -79,6 +82,7 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, env):
     nll, grad = RO.evaluate(np.log([0.45, 0.5]), mats, C, y, True, 50, perm=sym.P())
     f2 = sym.factorize([0.3, 0.7])
     for g in got:
+        assert np.array_equal(g["perm"], sym.P())
         assert abs(g["logdet"] - f.logdet()) < 1e-11 * abs(f.logdet())
         assert rel_err(g["X"], X) < 1e-10
         assert abs(g["nll"] - nll) < 1e-10 * abs(nll)
@@ -86,3 +90,49 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, env):
         assert abs(g["logdet2"] - f2.logdet()) < 1e-11 * abs(f2.logdet())
         assert rel_err(g["X2"], f2(B)) < 1e-10
         assert rel_err(g["Z2"], f2.lmul(B)) < 1e-10
+        first, Wg, G = (int(v) for v in g["params"])
+        assert int(g["nsuper"]) - first == 24 and Wg % world == 0 and G == 4 * Wg
+
+
+def _npd_worker(rank, world, port, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)
+    os.environ["SCILMM_TUNING"] = "1"
+    os.environ["SCILMM_DIST_GROUP"] = "2"
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scilmm_amd._lib import NotPositiveDefiniteError
+    from scilmm_amd.dist import HipChainEngine
+    rng = np.random.default_rng(0)
+    n = 1100
+    Gm = rng.standard_normal((n, n))
+    A = sp.csr_matrix(Gm @ Gm.T / n)       # dense: EVERY front is a distributed tail panel (9 of them, from level 0 on)
+    I = sp.eye(n).tocsr()
+    eng = HipChainEngine([A, I], rank, world, dist, "cuda:0", perm=np.arange(n))
+    raised = -2
+    try:
+        eng.factorize([1.0, -0.5])           # indefinite: the pivot fails inside ONE rank's panel
+    except NotPositiveDefiniteError as e:
+        raised = int(e.column)
+    eng.factorize([1.0, 0.5])                # ... and the handle is usable afterwards on every rank
+    b = np.random.default_rng(1).standard_normal((n, 3))
+    x = eng.solve(b)
+    V = (A + 0.5 * I).toarray()
+    np.savez(out % rank, raised=raised, resid=np.abs(V @ x - b).max(), logdet=eng.logdet(), ref=np.linalg.slogdet(V)[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_not_positive_definite_is_reported_by_every_rank(tmp_path):
+    """fac->status is written by the owner of the failing panel only -- it is now all-reduced (MIN)
+    through the communication callback, so every rank raises NotPositiveDefiniteError with the same column and none is
+    left waiting in the next collective.  ADVICE r2 (low): a matrix whose distributed part starts at level 0 (dense)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "npd%d.npz")
+    mp.spawn(_npd_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = [np.load(out % r) for r in range(2)]
+    assert got[0]["raised"] >= 0 and got[0]["raised"] == got[1]["raised"]
+    for g in got:
+        assert float(g["resid"]) < 1e-9 and abs(float(g["logdet"]) - float(g["ref"])) < 1e-9 * abs(float(g["ref"]))
