@@ -108,6 +108,8 @@ def _tail_worker(rank, world, port, out, which, group):
     import torch
     import torch.distributed as dist
     torch.set_num_threads(1)
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(limits=1)  # `world` processes share this machine's cores: one BLAS thread each
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["SCILMM_HOST_THREADS"] = "1"
