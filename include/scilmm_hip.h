@@ -214,7 +214,9 @@ typedef struct scilmm_timing {
 } scilmm_timing;
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
 /* Bracket every kernel class of the factorization with HIP events on the handle's stream (bench.py's
- * live roofline figure).  Off by default. */
+ * live roofline figure).  Off by default.  on = 2 additionally queues every look-ahead ("early") update launch on ONE
+ * side stream instead of alternating between two, so that the durations of consecutive launches of the dominant kernel
+ * do not overlap each other (the clean per-launch figure; slower as a whole -- a measurement mode, same results). */
 int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on);
 
 /* --- SURVEY section 8(f) rank 1 ("next"): pedigree -> IBD matrix, the producer of the hot path's input.

@@ -60,6 +60,7 @@ struct Dev {
   hipStream_t side2 = nullptr;     // early updates alternate between two side streams (their tails overlap)
   hipStream_t side3 = nullptr;     // optional third one (SCILMM_SIDE_STREAMS=3)
   int nside = 2;
+  bool serial_early = false;       // profiling mode 2: every early launch on ONE side stream (launch durations do not overlap)
   std::vector<hipEvent_t> lev_ev;  // 2 per level: [2l] = level l finished, [2l+1] = early update of level l finished
   hipEvent_t ev_asm = nullptr;
   hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;  // main <-> comm stream hand-offs (multi-GPU)
@@ -125,7 +126,7 @@ struct Dev {
   hipEvent_t out_ev = nullptr;
   bool dense_on = false;
   int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
-  double* d_zeros = nullptr;            // 2 KiB of zeros: source of the B k-rows past a descendant's end (k_dense_a)
+  double* d_zeros = nullptr;            // 2 KiB of zeros: source of the B k-rows past a descendant's end (k_dense_b)
   DenseWork* d_dwork_e = nullptr;
   DenseWork* d_dwork_l = nullptr;
   std::vector<int64_t> dwork_e_ptr, dwork_l_ptr;  // [nlevels+1]
@@ -624,7 +625,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     // path's (66 -> 72 ms), so it is switched on by the width of the tail.  SCILMM_DENSE=1 / 0 forces it.
     const char* edn = tune_env("SCILMM_DENSE");
     const int32_t tail_w = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
-    // (k_dense_a has no scalar form: with SCILMM_NO_MFMA=1 the tail goes through the explicit items of k_update2<false>)
+    // (k_dense_b has no scalar form: with SCILMM_NO_MFMA=1 the tail goes through the explicit items of k_update2<false>)
     D->dense_on = S.dense_first < S.nsuper && D->use_mfma && (edn ? edn[0] != '0' : tail_w >= 32768);
     // a distributed tail is always updated by the implicit items (the batches have no explicit-combo form)
     if (D->world > 1 && D->dist_first < S.nsuper) D->dense_on = true;
@@ -1105,7 +1106,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* eti = tune_env("SCILMM_TARGET_ITEMS");
     const char* emn = tune_env("SCILMM_MIN_ITEM");
     const char* edi = tune_env("SCILMM_DENSE_ITEMS");
-    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 2048);  // k_dense_a items per launch (target)
+    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 2048);  // k_dense_b items per launch (target)
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -1399,7 +1400,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         fprintf(stderr, "[scilmm plan] dense tail: %lld of %lld (target, descendant) panel pairs carry true entries, %lld of %lld target tile pairs are reached by a descendant (the others are padding only and skipped)\n",
                 (long long)dense_pairs_kept, (long long)dense_pairs_all, (long long)dense_tiles_kept, (long long)dense_tiles_all);
       if (getenv("SCILMM_VERBOSE"))
-        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense_a)\n",
+        fprintf(stderr, "[scilmm plan] dense tail: fronts %d..%d (%d wide), %lld early + %lld late implicit items (k_dense_b)\n",
                 S.dense_first, S.nsuper - 1, S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0,
                 (long long)D->dwork_e_ptr[S.nlevels], (long long)D->dwork_l_ptr[S.nlevels]);
     }
@@ -1616,7 +1617,7 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense_a, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
@@ -1764,7 +1765,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         hipLaunchKernelGGL(k_dense32, dim3(c), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
                            S.dense_first, dw + o, fac->L, scratch_half);
       else
-        hipLaunchKernelGGL(k_dense_a, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
+        hipLaunchKernelGGL(k_dense_b, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
                            fac->L, scratch_half, (const double*)D->d_zeros);
       launches++;
     }
@@ -1806,7 +1807,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   auto launch_early = [&](int32_t l) -> int {
     const int64_t e0 = D->early_ptr[l], e1 = D->early_ptr[l + 1];
     if (!has_early(l)) return SCILMM_OK;
-    const int sidx = l % D->nside;
+    const int sidx = D->serial_early ? 0 : l % D->nside;
     hipStream_t sd = sidx == 0 ? D->side : (sidx == 1 ? D->side2 : D->side3);
     // its youngest descendants sit look_depth + 1 levels below
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
@@ -2865,6 +2866,7 @@ int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on) {
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
   D->profiling = on != 0;
+  D->serial_early = on == 2;
   return SCILMM_OK;
 }
 

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update2(DevSy
 //   acc[256 x 128] = sum_d  L_d[rows of the two 128-row target tiles, :] * L_d[rows = target columns, :]^T
 // One workgroup = TWO vertically adjacent 128-row target tiles that share the B operand (the descendant rows at the
 // target's columns), one workgroup per CU so that the accumulators (64 doubles per lane) fit the register file.
-// k_dense_a is the fp64 form, k_dense32 the fp32-product form; the register-staged and the both-operands-by-DMA
+// k_dense_b is the fp64 form, k_dense32 the fp32-product form; the register-staged and the both-operands-by-DMA
 // predecessors live in csrc/tools/retired_kernels.hip.h (tuning harness only).
 struct DenseWork {
   int32_t front;       // target front j (>= dense_first)
@@ -469,38 +469,53 @@ struct DenseWork {
 #define SCILMM_DENSE_VEC 1  // 16-byte staging accesses (0: the 8-byte form)
 #endif
 constexpr int DTR = 2 * TM;        // rows per dense work item
+constexpr int KBA = 64;            // depth of a B buffer of the dense-tail kernel
 constexpr int LDA2 = DTR + 16;     // == 16 mod 32 doubles: conflict-free b64 fragment reads
 
 #ifdef SCILMM_DENSE_CLK
 __device__ unsigned long long g_dense_clk[2];  // tuning harness only: summed wall-clock (100 MHz) / shader-clock ticks of wave 0
 #endif
 
+// a wave-uniform pointer / integer moved to scalar registers (lets loads use the SGPR-base + 32-bit lane offset form)
+__device__ __forceinline__ int64_t uniform_i64(int64_t x) {
+  const uint64_t v = (uint64_t)x;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// element at byte offset voff8 (32-bit, per lane) from a wave-uniform base: SGPR base + VGPR offset addressing
+__device__ __forceinline__ double ld_off(const double* base, uint32_t voff8) {
+  return *(const double*)((const char*)base + voff8);
+}
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gl_vptr;
 
 // ------------------------------------------------------------------------------------------------
-// k_dense_a: the dense-tail update with ONLY the B operand in LDS.  A wave multiplies its own 32 rows and nobody
-// else's, so its A fragments need no sharing: they are loaded straight from the panel into registers (a lane's two
-// rows for its k of a k-step: 16 consecutive rows = 128 contiguous bytes per quarter wave), one 16-deep sub-chunk
-// ahead of their use.  LDS then holds B alone, 64 k-rows deep per buffer (2 x 64 x 144 doubles = 144 KB) and filled by
-// LDS-DMA (global_load_lds_dwordx4, gfx950: a wave-instruction moves 64 x 16 bytes from per-lane global addresses
-// straight into 1 KiB of contiguous LDS = one k-row of the B image; k-rows past the end of a descendant come from a
-// zero page): one barrier per 64 k, no A image to write or read, no staging registers.
-// (Measured and dropped: three register sets with the A loads TWO sub-chunks ahead -- 256 VGPRs, same 61.5 / 58.6
-// TFLOP/s alone: the loads cost issue and bandwidth, not latency.)
-#ifndef SCILMM_DENSE_A_ABL
-#define SCILMM_DENSE_A_ABL 0  // tuning harness only: 1 = A fragments loaded once per item (WRONG numbers; what do the loads cost?),
-                              // 2 = B copied once per item
+// k_dense_b: the dense-tail update with ONLY the B operand in LDS.  A wave multiplies its own 32 rows and nobody else's,
+// so its A fragments need no sharing: they are loaded straight from the panel into registers (16 consecutive rows = 128
+// contiguous bytes per quarter wave), one 16-deep sub-chunk ahead of their use.  LDS holds B alone, 64 k-rows deep per
+// buffer (2 x 64 x 144 doubles = 144 KB), filled by LDS-DMA (global_load_lds_dwordx4, gfx950: a wave-instruction moves
+// 64 x 16 bytes from per-lane global addresses straight into 1 KiB of contiguous LDS = one k-row of the B image; k-rows
+// past the end of a descendant come from a zero page): one barrier per 64 k, no A image, no staging registers.
+// Both operand streams are software-pipelined inside the wave (round 3; k_dense_a in csrc/tools/retired_kernels.hip.h is
+// the same kernel without that and gives the same bits: 56.9 -> 62.2 TFLOP/s alone on random operands, 62.5 -> 65.8 on
+// 48-descendant items, profiles/r3_k_dense_b_isolated.txt):
+//  * B fragments: the eight LDS reads of k-step t+1 are issued BETWEEN the MFMAs of k-step t (second register set), so a
+//    wave never sits at an lgkmcnt wait with an empty matrix pipe; the barrier of a chunk moves in front of its LAST
+//    k-step, whose fragments are already in registers: the first fragments of the next chunk are read, and the copy of
+//    the chunk after next is started, while that k-step multiplies.
+//  * A fragments: wave-uniform base (descendant panel + k * md in scalar registers) + one 32-bit lane offset per chunk
+//    (the SGPR-base addressing form): no 64-bit address arithmetic per load.  k-steps past a short chunk's end re-read
+//    its last 4-deep block (their B rows are the zero page's), at most 3 columns past the panel -- inside the slack the
+//    factor storage keeps behind every panel for exactly this kind of over-read.
+//  (Measured and dropped: a lane owning two ADJACENT rows, one 16-byte load per k -- 59.6 instead of 62.2 TFLOP/s.)
+#ifndef SCILMM_DENSE_B_SG
+#define SCILMM_DENSE_B_SG 1   // 1: interleave one LDS read with four MFMAs (sched_group_barrier); 0: leave it to the scheduler
 #endif
-constexpr int KBA = 64;  // depth of a B buffer of k_dense_a
-#ifndef SCILMM_DENSE_A_SCHED
-#define SCILMM_DENSE_A_SCHED 0  // tuning harness: 0 = scheduling barrier after every k-step, 1 = after every sub-chunk, 2 = every 2 k-steps
-                                // (alone, zero / random operands: 61.6 / 59.5, 61.0 / 58.6, 61.6 / 57.9 TFLOP/s -- no difference)
-#endif
-__global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+__global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
                                                     double* __restrict__ L, double* __restrict__ scratch,
                                                     const double* __restrict__ zeros) {
-  static_assert(NB == 128 && DTR == 256, "k_dense_a: 8 waves x 32 rows, one B k-row per DMA instruction");
+  static_assert(NB == 128 && DTR == 256, "k_dense_b: 8 waves x 32 rows, one B k-row per DMA instruction");
   extern __shared__ __attribute__((aligned(16))) double smem[];  // [2][KBA][LDB]
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
@@ -510,26 +525,28 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
   const int32_t mj = S.n - c0j;
   const int32_t R0 = wk.ti0 * TM;
   const int32_t nrow = min(wk.ntiles * TM, mj - R0);
-  const int32_t ra0 = R0 + (32 * wv + li < nrow ? 32 * wv + li : 0);
-  const int32_t ra1 = R0 + (32 * wv + 16 + li < nrow ? 32 * wv + 16 + li : 0);
+  // the two target rows of this lane inside the item (rows past the item's edge: row 0, never stored)
+  const int32_t ia = 32 * wv + li, ib_ = ia + 16;
+  const int32_t ra0 = R0 + (ia < nrow ? ia : 0);
+  const int32_t ra1 = R0 + (ib_ < nrow ? ib_ : 0);
   const int32_t b_off = 2 * lane < wj ? 2 * lane : 0;
   const double* zsrc = zeros + 2 * lane;
-  struct Chunk { const double* Pd; int64_t md; int kc; };
+  struct Chunk { const double* Pd; int32_t md; int kc; uint32_t v0, v1; };
   int32_t kd = wk.k0, kk0 = 0;
-  bool first_a = true, first_b = true;  // (only read by the tuning-harness ablations)
   auto next_chunk = [&]() {
     const int32_t d = dense_first + kd;
     const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
     Chunk c;
-    c.md = S.n - c0d;
-    c.Pd = L + S.sn_loff[d] + (int64_t)kk0 * c.md + (c0j - c0d);
-    c.kc = min(KBA, wd - kk0);
+    c.md = __builtin_amdgcn_readfirstlane(S.n - c0d);
+    c.Pd = L + uniform_i64(S.sn_loff[d] + (int64_t)kk0 * c.md + (c0j - c0d));
+    c.kc = __builtin_amdgcn_readfirstlane(min(KBA, wd - kk0));
+    c.v0 = (uint32_t)(lk * c.md + ra0) * 8u;  // byte offsets of this lane's rows in the k-column lk of a 4-deep block
+    c.v1 = (uint32_t)(lk * c.md + ra1) * 8u;
     kk0 += KBA;
     if (kk0 >= wd) { kk0 = 0; ++kd; }
     return c;
   };
   auto issue_B = [&](const Chunk& c, int b) {
-    if (SCILMM_DENSE_A_ABL == 2 && !first_b) return;
     double* Bs = smem + b * KBA * LDB;
 #pragma unroll
     for (int i = 0; i < KBA / 8; ++i) {
@@ -538,12 +555,12 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
     }
   };
   auto load_A = [&](const Chunk& c, int s, double (&ra)[4][2]) {
-    if (SCILMM_DENSE_A_ABL == 1 && !first_a) return;
+    const int klast = (c.kc - 1) & ~3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double* p = c.Pd + (int64_t)min(16 * s + 4 * q + lk, c.kc - 1) * c.md;  // past the end: any valid column (B is 0 there)
-      ra[q][0] = p[ra0];
-      ra[q][1] = p[ra1];
+      const double* sp = c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md;  // wave-uniform
+      ra[q][0] = ld_off(sp, c.v0);
+      ra[q][1] = ld_off(sp, c.v1);
     }
   };
   d4 acc16[NJB][2];
@@ -551,64 +568,74 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
   for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
   if (wk.k0 >= wk.k1) return;
   double rA[2][4][2];
+  double bf[2][NJB];
+  auto ldB = [&](const double* Bc, int k4, double (&b)[NJB]) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
+  };
+  auto mma = [&](const double (&b)[NJB], double a0, double a1) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+      acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
+      acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
+    }
+  };
   Chunk cur = next_chunk();
   issue_B(cur, 0);
   load_A(cur, 0, rA[0]);
-  if (SCILMM_DENSE_A_ABL == 1) { load_A(cur, 1, rA[1]); first_a = false; }
-  first_b = false;
+  bool more = kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
+  ldB(smem, 0, bf[0]);
   while (true) {
-    const bool more = kd < wk.k1;
-    Chunk nxt = cur;
-    if (more) {
-      nxt = next_chunk();
-      issue_B(nxt, buf ^ 1);
-    }
     const double* Bc = smem + buf * KBA * LDB;
-    auto kstep = [&](int k4, double a0, double a1) {
-      double b[NJB];
+    const double* Bn = smem + (buf ^ 1) * KBA * LDB;
+    bool more2 = false;
+    Chunk nn = nxt;
 #pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
-#pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
-        acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
-        acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
+    for (int t = 0; t < 16; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+        // the A fragments of the next sub-chunk (or of the next chunk's first one): one sub-chunk of MFMA time ahead
+        if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
       }
-#if SCILMM_DENSE_A_SCHED == 0
-      __builtin_amdgcn_sched_barrier(0);  // keep the k-steps apart: unrolled 16 deep, the scheduler otherwise hoists every
-                                          // fragment read to the top and spills 149 registers
+      if (t < 15) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        // chunk boundary: every wave has READ its last fragments of Bc (they are in registers) and the copy of the next
+        // chunk has landed -- after this barrier Bn may be read and Bc overwritten
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.k1;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+      mma(bf[t & 1], rA[s & 1][q][0], rA[s & 1][q][1]);
+#if SCILMM_DENSE_B_SG
+      if (t < 15) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read (two fragments) ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // ... behind four MFMAs
+        }
+      }
 #endif
-    };
-    {
-      // sub-chunk s + 1 (or sub-chunk 0 of the next chunk) is in flight while sub-chunk s is multiplied.  A chunk shorter
-      // than 64 (last chunk of a descendant whose width is no multiple of 64 -- rare) runs the same 16 k-steps: its B
-      // k-rows past the end are zero, its A loads re-read the last column.  (A separate rolled loop for it cost the
-      // common path its registers: 156 spills.)
-#if SCILMM_DENSE_A_SCHED == 1
-#define SCILMM_SUBSYNC(q) if ((q) == 3) __builtin_amdgcn_sched_barrier(0)
-#elif SCILMM_DENSE_A_SCHED == 2
-#define SCILMM_SUBSYNC(q) if ((q) & 1) __builtin_amdgcn_sched_barrier(0)
-#else
-#define SCILMM_SUBSYNC(q)
-#endif
-      load_A(cur, 1, rA[1]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { kstep(4 * q, rA[0][q][0], rA[0][q][1]); SCILMM_SUBSYNC(q); }
-      load_A(cur, 2, rA[0]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { kstep(16 + 4 * q, rA[1][q][0], rA[1][q][1]); SCILMM_SUBSYNC(q); }
-      load_A(cur, 3, rA[1]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { kstep(32 + 4 * q, rA[0][q][0], rA[0][q][1]); SCILMM_SUBSYNC(q); }
-      if (more) load_A(nxt, 0, rA[0]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { kstep(48 + 4 * q, rA[1][q][0], rA[1][q][1]); SCILMM_SUBSYNC(q); }
-#undef SCILMM_SUBSYNC
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (!more) break;
     cur = nxt;
-    __syncthreads();
+    nxt = nn;
+    more = more2;
     buf ^= 1;
   }
   double* P = L + S.sn_loff[j];
@@ -618,7 +645,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = 32 * wv + 16 * ib + li, jc = 16 * jb + lk + 4 * r;
+        const int i = ib == 0 ? ia : ib_, jc = 16 * jb + lk + 4 * r;
         const double v = acc16[jb][ib][r];
         const int h = i >> 7;
         const int32_t slot = h ? wk.slot1 : wk.slot0;
@@ -1654,17 +1681,6 @@ struct ChainPair {
   int32_t map;    // jp0 < 0, forward: offset into the column -> row map (NB entries, -1 = no such row)
 };
 
-// a wave-uniform pointer / integer moved to scalar registers (lets loads use the SGPR-base + 32-bit lane offset form)
-__device__ __forceinline__ int64_t uniform_i64(int64_t x) {
-  const uint64_t v = (uint64_t)x;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-// element at byte offset voff8 (32-bit, per lane) from a wave-uniform base: SGPR base + VGPR offset addressing
-__device__ __forceinline__ double ld_off(const double* base, uint32_t voff8) {
-  return *(const double*)((const char*)base + voff8);
-}
-__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ bool chain_wait(const int32_t* flag, int32_t epoch, int32_t* err, int behind) {
   // one thread spins; returns false on timeout / earlier error (the caller then leaves quietly).  `behind` = how

@@ -1,7 +1,7 @@
 // Kernel-tuning harness: k_dense (csrc/kernels.hip.h) ALONE on a synthetic dense tail -- one level's early update
 // (target panel j of a T-panel dense lower-triangular matrix, all tile pairs, K split into segments), no other
 // stream, no host logic.  Prints the sustained TFLOP/s of the launch for both f64 MFMA forms.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I.. dense_bench.hip -o dense_bench && ./dense_bench [T] [j] [panels per item]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DSCILMM_DENSE_CLK dense_bench.hip -o dense_bench && ./dense_bench [T] [j] [panels per item]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

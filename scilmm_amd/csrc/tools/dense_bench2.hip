@@ -1,0 +1,108 @@
+// Kernel-tuning harness, round 3: k_dense_a against k_dense_b (csrc/kernels.hip.h) ALONE on a synthetic dense tail -- one
+// level's early update (target panel j of a T-panel dense lower-triangular matrix, all tile pairs, K split into segments
+// of `per` descendants), no other stream, no host logic.  Prints the sustained TFLOP/s of the launch for zero and random
+// operands (zeros read HIGH: zero MFMA operands raise the clock) and checks that both kernels write the same bits.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DSCILMM_DENSE_B_SG=0] [-DSCILMM_DENSE_B_X4=1] dense_bench2.hip -o dense_bench2
+//   ./dense_bench2 [T] [j] [panels per item]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include "retired_kernels.hip.h"
+using namespace scilmm;
+
+__global__ void k_fill(double* p, size_t n, int mode) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long x = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+    p[i] = mode == 0 ? 0.0 : ((double)(x >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0;
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  const int T = argc > 1 ? atoi(argv[1]) : 400;        // panels of the tail
+  const int j = argc > 2 ? atoi(argv[2]) : 300;        // target panel
+  const int per = argc > 3 ? atoi(argv[3]) : 10;       // descendants per item
+  const int wlast = argc > 4 ? atoi(argv[4]) : NB;     // width of every 7th descendant (short chunks: < 128, not a multiple of 64)
+  std::vector<int32_t> sn_start(T + 1, 0);
+  for (int k = 0; k < T; ++k) sn_start[k + 1] = sn_start[k] + ((k % 7 == 3) ? wlast : NB);
+  const int n = sn_start[T];
+  std::vector<int64_t> sn_loff(T + 1, 0);
+  for (int k = 0; k < T; ++k) sn_loff[k + 1] = sn_loff[k] + (((int64_t)(n - sn_start[k]) * (sn_start[k + 1] - sn_start[k]) + 1) & ~(int64_t)1);
+  double* L;
+  const size_t nL = (size_t)sn_loff[T] + 4 * (size_t)n + 4 * NB;
+  CK(hipMalloc(&L, sizeof(double) * nL));
+  DevSym S{};
+  S.n = n;
+  S.nsuper = T;
+  int32_t* d_start; int64_t* d_loff;
+  CK(hipMalloc(&d_start, sizeof(int32_t) * (T + 1)));
+  CK(hipMalloc(&d_loff, sizeof(int64_t) * (T + 1)));
+  CK(hipMemcpy(d_start, sn_start.data(), sizeof(int32_t) * (T + 1), hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_loff, sn_loff.data(), sizeof(int64_t) * (T + 1), hipMemcpyHostToDevice));
+  S.sn_start = d_start;
+  S.sn_loff = d_loff;
+  std::vector<DenseWork> work;
+  const int mj = n - sn_start[j];
+  const int ntl = (mj + TM - 1) / TM;  // tiles of panel j
+  int slot = 0;
+  for (int k0 = 0; k0 < j; k0 += per)  // K-segment major, tile-pair minor (the engine's launch order)
+    for (int q = 0; q < ntl; q += 2) {
+      const int nt2 = ntl - q >= 2 ? 2 : 1;
+      DenseWork w{j, q, nt2, k0, k0 + per < j ? k0 + per : j, slot, nt2 == 2 ? slot + 1 : -1, 0};
+      slot += 2;
+      work.push_back(w);
+    }
+  DenseWork* d_work;
+  CK(hipMalloc(&d_work, sizeof(DenseWork) * work.size()));
+  CK(hipMemcpy(d_work, work.data(), sizeof(DenseWork) * work.size(), hipMemcpyHostToDevice));
+  double* scratch;
+  CK(hipMalloc(&scratch, sizeof(double) * (size_t)slot * TM * NB));
+  CK(hipFuncSetAttribute((const void*)k_dense_a, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_dense_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  double* zeros;
+  CK(hipMalloc(&zeros, 2048));
+  CK(hipMemset(zeros, 0, 2048));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  double flops = 0;
+  for (auto& w : work)
+    for (int d = w.k0; d < w.k1; ++d) flops += 2.0 * std::min(w.ntiles * TM, mj - w.ti0 * TM) * (double)(sn_start[j + 1] - sn_start[j]) * (sn_start[d + 1] - sn_start[d]);
+  printf("T=%d panels (every 7th %d wide), target %d: %zu items (%d descendants each), %.3f TFLOP per launch; k_dense_b: SG=%d X4=%d\n", T, wlast, j,
+         work.size(), per, flops / 1e12, SCILMM_DENSE_B_SG, 0);
+  const size_t smb = sizeof(double) * 2 * KBA * LDB;
+  for (int fill : {0, 1})
+  for (int which : {0, 1}) {
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, nL, fill);
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0);
+      if (which == 0) hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      else hipLaunchKernelGGL(k_dense_b, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      CK(hipGetLastError());
+      if (rep) printf("%s, %s operands: %.3f ms -> %.2f TFLOP/s\n", which ? "k_dense_b" : "k_dense_a", fill ? "random" : "zero", ms, flops / ms / 1e9);
+    }
+  }
+  {
+    const size_t ns = (size_t)slot * TM * NB;
+    std::vector<double> r0(ns), r1(ns);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, nL, 1);
+    CK(hipMemset(scratch, 0, sizeof(double) * ns));
+    hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+    CK(hipMemcpy(r0.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    CK(hipMemset(scratch, 0, sizeof(double) * ns));
+    hipLaunchKernelGGL(k_dense_b, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+    CK(hipMemcpy(r1.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
+    double mx = 0, ref = 0;
+    for (size_t i = 0; i < ns; ++i) { mx = std::max(mx, std::fabs(r0[i] - r1[i])); ref = std::max(ref, std::fabs(r0[i])); }
+    printf("k_dense_b vs k_dense_a: max |difference| of the slabs %.3g (largest entry %.3g)\n", mx, ref);
+  }
+  return 0;
+}

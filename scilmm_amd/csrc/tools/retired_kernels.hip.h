@@ -5,6 +5,7 @@
 //   k_update3       -> k_update2   (the v_mfma_f64_4x4x4 form: 67.5 vs 66.2 ms at 100k)
 //   k_dense<MF>     -> k_dense_a   (register-staged dense-tail update, both f64 MFMA forms)
 //   k_dense_g       -> k_dense_a   (both operands by LDS-DMA)
+//   k_dense_a       -> k_dense_b   (A from registers, B by LDS-DMA, without the in-wave software pipeline of round 3)
 //   k_update_compact               (compact-coordinate update: 66 -> 91..96 ms at 100k)
 //   k_trsm4         -> k_trsm      (the 4x4x4 form)
 // Include AFTER ../kernels.hip.h.
@@ -1000,5 +1001,157 @@ __global__ __launch_bounds__(256) void k_trsm4(DevSym S, const int32_t* __restri
       if (i < nrow && R0 + i >= w && j < w) P[(int64_t)j * m + R0 + i] = acc4[pr][q4];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_dense_a: the dense-tail update with ONLY the B operand in LDS.  A wave multiplies its own 32 rows and nobody
+// else's, so its A fragments need no sharing: they are loaded straight from the panel into registers (a lane's two
+// rows for its k of a k-step: 16 consecutive rows = 128 contiguous bytes per quarter wave), one 16-deep sub-chunk
+// ahead of their use.  LDS then holds B alone, 64 k-rows deep per buffer (2 x 64 x 144 doubles = 144 KB) and filled by
+// LDS-DMA (global_load_lds_dwordx4, gfx950: a wave-instruction moves 64 x 16 bytes from per-lane global addresses
+// straight into 1 KiB of contiguous LDS = one k-row of the B image; k-rows past the end of a descendant come from a
+// zero page): one barrier per 64 k, no A image to write or read, no staging registers.
+// (Measured and dropped: three register sets with the A loads TWO sub-chunks ahead -- 256 VGPRs, same 61.5 / 58.6
+// TFLOP/s alone: the loads cost issue and bandwidth, not latency.)
+#ifndef SCILMM_DENSE_A_ABL
+#define SCILMM_DENSE_A_ABL 0  // tuning harness only: 1 = A fragments loaded once per item (WRONG numbers; what do the loads cost?),
+                              // 2 = B copied once per item
+#endif
+#ifndef SCILMM_DENSE_A_SCHED
+#define SCILMM_DENSE_A_SCHED 0  // tuning harness: 0 = scheduling barrier after every k-step, 1 = after every sub-chunk, 2 = every 2 k-steps
+                                // (alone, zero / random operands: 61.6 / 59.5, 61.0 / 58.6, 61.6 / 57.9 TFLOP/s -- no difference)
+#endif
+__global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, double* __restrict__ scratch,
+                                                    const double* __restrict__ zeros) {
+  static_assert(NB == 128 && DTR == 256, "k_dense_a: 8 waves x 32 rows, one B k-row per DMA instruction");
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [2][KBA][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  const int32_t ra0 = R0 + (32 * wv + li < nrow ? 32 * wv + li : 0);
+  const int32_t ra1 = R0 + (32 * wv + 16 + li < nrow ? 32 * wv + 16 + li : 0);
+  const int32_t b_off = 2 * lane < wj ? 2 * lane : 0;
+  const double* zsrc = zeros + 2 * lane;
+  struct Chunk { const double* Pd; int64_t md; int kc; };
+  int32_t kd = wk.k0, kk0 = 0;
+  bool first_a = true, first_b = true;  // (only read by the tuning-harness ablations)
+  auto next_chunk = [&]() {
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    Chunk c;
+    c.md = S.n - c0d;
+    c.Pd = L + S.sn_loff[d] + (int64_t)kk0 * c.md + (c0j - c0d);
+    c.kc = min(KBA, wd - kk0);
+    kk0 += KBA;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    if (SCILMM_DENSE_A_ABL == 2 && !first_b) return;
+    double* Bs = smem + b * KBA * LDB;
+#pragma unroll
+    for (int i = 0; i < KBA / 8; ++i) {
+      const int kr = wv + 8 * i;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(kr < c.kc ? c.Pd + (int64_t)kr * c.md + b_off : zsrc), (lds_vptr)(Bs + kr * LDB), 16, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int s, double (&ra)[4][2]) {
+    if (SCILMM_DENSE_A_ABL == 1 && !first_a) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* p = c.Pd + (int64_t)min(16 * s + 4 * q + lk, c.kc - 1) * c.md;  // past the end: any valid column (B is 0 there)
+      ra[q][0] = p[ra0];
+      ra[q][1] = p[ra1];
+    }
+  };
+  d4 acc16[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  if (wk.k0 >= wk.k1) return;
+  double rA[2][4][2];
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  if (SCILMM_DENSE_A_ABL == 1) { load_A(cur, 1, rA[1]); first_a = false; }
+  first_b = false;
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    const bool more = kd < wk.k1;
+    Chunk nxt = cur;
+    if (more) {
+      nxt = next_chunk();
+      issue_B(nxt, buf ^ 1);
+    }
+    const double* Bc = smem + buf * KBA * LDB;
+    auto kstep = [&](int k4, double a0, double a1) {
+      double b[NJB];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
+        acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
+      }
+#if SCILMM_DENSE_A_SCHED == 0
+      __builtin_amdgcn_sched_barrier(0);  // keep the k-steps apart: unrolled 16 deep, the scheduler otherwise hoists every
+                                          // fragment read to the top and spills 149 registers
+#endif
+    };
+    {
+      // sub-chunk s + 1 (or sub-chunk 0 of the next chunk) is in flight while sub-chunk s is multiplied.  A chunk shorter
+      // than 64 (last chunk of a descendant whose width is no multiple of 64 -- rare) runs the same 16 k-steps: its B
+      // k-rows past the end are zero, its A loads re-read the last column.  (A separate rolled loop for it cost the
+      // common path its registers: 156 spills.)
+#if SCILMM_DENSE_A_SCHED == 1
+#define SCILMM_SUBSYNC(q) if ((q) == 3) __builtin_amdgcn_sched_barrier(0)
+#elif SCILMM_DENSE_A_SCHED == 2
+#define SCILMM_SUBSYNC(q) if ((q) & 1) __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCILMM_SUBSYNC(q)
+#endif
+      load_A(cur, 1, rA[1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { kstep(4 * q, rA[0][q][0], rA[0][q][1]); SCILMM_SUBSYNC(q); }
+      load_A(cur, 2, rA[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { kstep(16 + 4 * q, rA[1][q][0], rA[1][q][1]); SCILMM_SUBSYNC(q); }
+      load_A(cur, 3, rA[1]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { kstep(32 + 4 * q, rA[0][q][0], rA[0][q][1]); SCILMM_SUBSYNC(q); }
+      if (more) load_A(nxt, 0, rA[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { kstep(48 + 4 * q, rA[1][q][0], rA[1][q][1]); SCILMM_SUBSYNC(q); }
+#undef SCILMM_SUBSYNC
+    }
+    if (!more) break;
+    cur = nxt;
+    __syncthreads();
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 32 * wv + 16 * ib + li, jc = 16 * jb + lk + 4 * r;
+        const double v = acc16[jb][ib][r];
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+        }
+      }
+}
+
 
 }  // namespace scilmm

@@ -119,7 +119,9 @@ class Symbolic(object):
         self.front_bits = int(bits)
 
     def set_profiling(self, on=True):
-        check(lib().scilmm_set_profiling(self._h, int(bool(on))), self._h)
+        """True / 1: HIP-event brackets per kernel class; 2: also queue the look-ahead launches on one stream (clean
+        per-launch durations of the dominant kernel; a measurement mode)."""
+        check(lib().scilmm_set_profiling(self._h, 2 if on == 2 else int(bool(on))), self._h)
 
     def sync(self):
         check(lib().scilmm_sync(self._h), self._h)
