@@ -224,12 +224,25 @@ int scilmm_set_profiling(scilmm_symbolic* sym, int32_t on);
  * Relationship.count_IBD_nonzero (scilmm/Matrices/Relationship.py:38-61).  parents: n x 2 int32, -1 = unknown,
  * individuals in topological order (parents first).  Host C++/OpenMP; no device needed. */
 typedef struct scilmm_ibd scilmm_ibd;
+/* count_only: 0 = pattern + values, 1 = the number of structural nonzeros only, 2 = the PATTERN only (no values: what the
+ * symbolic analysis needs when the values are then computed on the device, scilmm_ibd_values_device) */
 int scilmm_ibd_build(int32_t n, const int32_t* parents, int32_t count_only, scilmm_ibd** out, int64_t* nnz);
 int scilmm_ibd_sizes(const scilmm_ibd* h, int64_t* nnz_A, int64_t* nnz_L);
 /* A: symmetric CSR (both triangles, sorted); L: ancestor-weight rows; D, F: length n.  NULL pointers are skipped. */
 int scilmm_ibd_export(const scilmm_ibd* h, int64_t* a_indptr, int32_t* a_indices, double* a_data, int64_t* l_indptr,
                       int32_t* l_indices, double* l_data, double* D, double* F);
 void scilmm_ibd_free(scilmm_ibd* h);
+/* The VALUES of the IBD matrix computed on the device, straight into the HBM-resident value slots of matrix k of `sym` --
+ * they never exist on the host and never cross PCIe (replaces create_numerator's L D L^T, Numerator.py:37-38, and the
+ * 8 bytes per entry of scilmm_values_upload: 7.3 GB at the 1M config).  Tabular recursion on the analysed pattern,
+ * A[i,j] = 1/2 (A[f_i,j] + A[m_i,j]) for i > j, A[i,i] = 1 + 1/2 A[f_i,m_i], one launch per generation sum (every entry
+ * depends on entries with a smaller gen(a) + gen(b) only).  parents: n x 2, -1 = unknown, individuals in pedigree order
+ * (the row order of the matrices given to scilmm_symbolic_create); the analysed pattern must contain every pair with a
+ * common ancestor (scilmm_ibd_build's pattern does).  Exact: the values are dyadic rationals. */
+int scilmm_ibd_values_device(scilmm_symbolic* sym, int32_t k, int32_t n, const int32_t* parents);
+/* Matrix k's device-resident values in PATTERN-SLOT order (scilmm_symbolic_get "pat_colptr" / "pat_row": permuted CSC of
+ * the lower triangle, diagonal first; n values for a diagonal-only matrix) -- for tests and diagnostics. */
+int scilmm_values_download(scilmm_symbolic* sym, int32_t k, double* slots_out);
 
 /* --- the on-disk format in front of the path.  Replaces scipy.io.mmread(path).tocsr()
  * (scilmm/SparseCholesky.py:399) by a memory-mapped, all-cores parse of the MatrixMarket coordinate file (real /

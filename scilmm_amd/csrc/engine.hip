@@ -2830,6 +2830,107 @@ int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double
   return SCILMM_OK;
 }
 
+int scilmm_ibd_values_device(scilmm_symbolic* sym, int32_t k, int32_t n, const int32_t* parents) {
+  if (!sym || !sym->S || !parents) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  const Symbolic& S = *sym->S;
+  if (k < 0 || k >= S.K || n != S.n || S.is_diag[k]) return SCILMM_ERR_ARG;
+  if (S.nnz_pattern >= ((int64_t)1 << 32)) {
+    sym->err = "scilmm_ibd_values_device: more than 2^32 pattern slots";
+    return SCILMM_ERR_ARG;
+  }
+  // generation (longest path from a founder) of every individual; individuals must be in pedigree order
+  std::vector<int32_t> gen((size_t)n, 0);
+  int32_t maxgen = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    int32_t g = 0;
+    for (int q = 0; q < 2; ++q) {
+      const int32_t p = parents[2 * i + q];
+      if (p >= i) {
+        sym->err = "scilmm_ibd_values_device: individuals are not in pedigree order (a parent follows its child)";
+        return SCILMM_ERR_ARG;
+      }
+      if (p >= 0) g = std::max(g, gen[p] + 1);
+    }
+    gen[i] = g;
+    maxgen = std::max(maxgen, g);
+  }
+  if (2 * maxgen > 254) {
+    sym->err = "scilmm_ibd_values_device: pedigree deeper than 127 generations";
+    return SCILMM_ERR_ARG;
+  }
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  hipStream_t s0 = D->stream;
+  const int64_t nnz = S.nnz_pattern;
+  std::vector<void*> tmp;
+  struct Cleanup {
+    std::vector<void*>& v;
+    ~Cleanup() { for (void* p : v) (void)hipFree(p); }
+  } cleanup{tmp};
+  auto tmalloc = [&](void** p, size_t bytes) -> int {
+    HIPCHK(hipMalloc(p, std::max<size_t>(bytes, 8)));
+    tmp.push_back(*p);
+    return SCILMM_OK;
+  };
+  int32_t *d_gen = nullptr, *d_par = nullptr, *d_iperm = nullptr;
+  uint8_t *key = nullptr, *skey = nullptr;
+  uint32_t *slot = nullptr, *sslot = nullptr;
+  int64_t* d_pass = nullptr;
+  if ((st = tmalloc((void**)&d_gen, sizeof(int32_t) * (size_t)n)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&d_par, sizeof(int32_t) * 2 * (size_t)n)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&d_iperm, sizeof(int32_t) * (size_t)n)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&key, (size_t)nnz)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&skey, (size_t)nnz)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&slot, sizeof(uint32_t) * (size_t)nnz)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&sslot, sizeof(uint32_t) * (size_t)nnz)) != SCILMM_OK) return st;
+  if ((st = tmalloc((void**)&d_pass, sizeof(int64_t) * 256)) != SCILMM_OK) return st;
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(d_gen, gen.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s0));
+    HIPCHK(hipMemcpyAsync(d_par, parents, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyHostToDevice, s0));
+    HIPCHK(hipMemcpyAsync(d_iperm, S.iperm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s0));
+  }
+  if (!D->vals[k]) HIPCHK(hipMalloc((void**)&D->vals[k], std::max<size_t>((size_t)nnz, 1) * sizeof(double)));
+  if (nnz > 0) {
+    hipLaunchKernelGGL(k_ibd_keys, dim3(4096), dim3(256), 0, s0, n, D->v.pat_colptr, D->v.pat_row, D->v.perm, (const int32_t*)d_gen, key, slot);
+    size_t need = 0;
+    void* cub = nullptr;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key, skey, slot, sslot, nnz, 0, 8, s0));
+    if ((st = tmalloc(&cub, need)) != SCILMM_OK) return st;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub, need, key, skey, slot, sslot, nnz, 0, 8, s0));
+    HIPCHK(hipMemsetAsync(d_pass, 0xff, sizeof(int64_t) * 256, s0));  // -1 = key absent
+    hipLaunchKernelGGL(k_ibd_bounds, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s0, nnz, (const uint8_t*)skey, d_pass);
+    std::vector<int64_t> pass(257, -1);
+    HIPCHK(hipMemcpyAsync(pass.data(), d_pass, sizeof(int64_t) * 256, hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipStreamSynchronize(s0));
+    pass[256] = nnz;
+    for (int q = 255; q >= 0; --q)
+      if (pass[q] < 0) pass[q] = pass[q + 1];
+    for (int q = 0; q <= 2 * maxgen; ++q) {
+      const int64_t cnt = pass[q + 1] - pass[q];
+      if (cnt <= 0) continue;
+      hipLaunchKernelGGL(k_ibd_pass, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s0, cnt, (const uint32_t*)(sslot + pass[q]), n,
+                         D->v.pat_colptr, D->v.pat_row, D->v.perm, (const int32_t*)d_iperm, (const int32_t*)d_par, D->vals[k]);
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s0));
+  HIPCHK(hipGetLastError());
+  D->have_vals[k] = 1;
+  return SCILMM_OK;
+}
+
+int scilmm_values_download(scilmm_symbolic* sym, int32_t k, double* slots_out) {
+  if (!sym || !sym->S || !sym->device || !slots_out) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  if (k < 0 || k >= S.K || !D->have_vals[k]) return SCILMM_ERR_STATE;
+  const size_t cnt = S.is_diag[k] ? (size_t)S.n : (size_t)S.nnz_pattern;
+  HIPCHK(hipMemcpy(slots_out, D->vals[k], cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return SCILMM_OK;
+}
+
 int scilmm_sync(scilmm_symbolic* sym) {
   if (!sym || !sym->device) return SCILMM_ERR_ARG;
   DevGuard guard(sym);

@@ -105,7 +105,7 @@ int build_L(Ibd& B, const int32_t* par) {
 }
 
 // A = L D L^T.  count_only: just the number of structural nonzeros (both triangles).
-int64_t build_A(Ibd& B, bool count_only) {
+int64_t build_A(Ibd& B, bool count_only, bool pattern_only = false) {
   const int32_t n = B.n;
   const bool verbose = getenv("SCILMM_VERBOSE") != nullptr;
   auto tlast = std::chrono::steady_clock::now();
@@ -133,7 +133,7 @@ int64_t build_A(Ibd& B, bool count_only) {
   // lower triangle row by row with a dense accumulator per thread
   std::vector<int64_t> lowcnt(n, 0);
   std::vector<std::vector<int32_t>> lowidx(count_only ? 0 : n);
-  std::vector<std::vector<double>> lowval(count_only ? 0 : n);
+  std::vector<std::vector<double>> lowval((count_only || pattern_only) ? 0 : n);
 #pragma omp parallel
   {
     std::vector<double> acc(n, 0.0);
@@ -159,8 +159,10 @@ int64_t build_A(Ibd& B, bool count_only) {
       if (!count_only) {
         std::sort(touched.begin(), touched.end());
         lowidx[i] = touched;
-        lowval[i].resize(touched.size());
-        for (size_t k = 0; k < touched.size(); ++k) lowval[i][k] = acc[touched[k]];
+        if (!pattern_only) {
+          lowval[i].resize(touched.size());
+          for (size_t k = 0; k < touched.size(); ++k) lowval[i][k] = acc[touched[k]];
+        }
       }
     }
   }
@@ -177,13 +179,13 @@ int64_t build_A(Ibd& B, bool count_only) {
   B.aptr.assign(n + 1, 0);
   for (int32_t i = 0; i < n; ++i) B.aptr[i + 1] = B.aptr[i] + lowcnt[i] + upcnt[i];
   B.aidx.resize(B.aptr[n]);
-  B.aval.resize(B.aptr[n]);
+  if (!pattern_only) B.aval.resize(B.aptr[n]);
   lap("count upper");
   std::vector<int64_t> fill(n);
 #pragma omp parallel for schedule(static)
   for (int32_t i = 0; i < n; ++i) {
     std::copy(lowidx[i].begin(), lowidx[i].end(), B.aidx.begin() + B.aptr[i]);
-    std::copy(lowval[i].begin(), lowval[i].end(), B.aval.begin() + B.aptr[i]);
+    if (!pattern_only) std::copy(lowval[i].begin(), lowval[i].end(), B.aval.begin() + B.aptr[i]);
     fill[i] = B.aptr[i] + lowcnt[i];
   }
   lap("copy lower");
@@ -193,7 +195,7 @@ int64_t build_A(Ibd& B, bool count_only) {
       if (j == i) continue;
       const int64_t f = fill[j]++;
       B.aidx[f] = i;
-      B.aval[f] = lowval[i][k];
+      if (!pattern_only) B.aval[f] = lowval[i][k];
     }
   lap("scatter upper");
   return both;
@@ -217,7 +219,7 @@ int scilmm_ibd_build(int32_t n, const int32_t* parents, int32_t count_only, scil
     delete h;
     return st;
   }
-  *nnz = build_A(h->B, count_only != 0);
+  *nnz = build_A(h->B, count_only == 1, count_only == 2);
   *out = h;
   return SCILMM_OK;
 }
@@ -237,7 +239,7 @@ int scilmm_ibd_export(const scilmm_ibd* h, int64_t* a_indptr, int32_t* a_indices
   if (a_indptr && !B.aptr.empty()) {
     std::memcpy(a_indptr, B.aptr.data(), sizeof(int64_t) * (n + 1));
     if (a_indices) std::memcpy(a_indices, B.aidx.data(), sizeof(int32_t) * B.aidx.size());
-    if (a_data) std::memcpy(a_data, B.aval.data(), sizeof(double) * B.aval.size());
+    if (a_data && !B.aval.empty()) std::memcpy(a_data, B.aval.data(), sizeof(double) * B.aval.size());
   }
   if (l_indptr) {
     std::memcpy(l_indptr, B.lptr.data(), sizeof(int64_t) * (n + 1));

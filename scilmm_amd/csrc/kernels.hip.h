@@ -2108,4 +2108,70 @@ __global__ __launch_bounds__(256) void k_dot_diag(int32_t n, const int64_t* __re
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// IBD (numerator relationship) values ON THE DEVICE, straight into the value slots of the engine (SURVEY 8f rank 1;
+// reference scilmm/Matrices/Numerator.py:5-38 computes A = L D L^T in interpreted Python).  Tabular recursion on the
+// known pattern (pairs with a common ancestor): for individuals i > j in pedigree order (parents before children, so i
+// is never an ancestor of j)
+//     A[i, j] = 1/2 (A[f_i, j] + A[m_i, j]),      A[i, i] = 1 + 1/2 A[f_i, m_i],      unknown parent: 0,
+// where the entries on the right are looked up (bisection in a sorted pattern column, like csrc/dominance.hip) among the
+// slots already computed.  An entry depends only on entries whose generation SUM gen(a) + gen(b) is smaller, so the slots
+// are sorted by that sum once (one radix-sort pass) and each sum is one launch: ~2 x generations launches, every slot
+// written exactly once, no atomics.  Values are dyadic rationals: halving and adding them is exact.
+__global__ __launch_bounds__(256) void k_ibd_keys(int32_t n, const int64_t* __restrict__ colptr, const int32_t* __restrict__ prow,
+                                                  const int32_t* __restrict__ perm, const int32_t* __restrict__ gen,
+                                                  uint8_t* __restrict__ key, uint32_t* __restrict__ slot) {
+  // one wave per pattern column c (permuted labels): key = generation sum of the pair, slot = identity
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = wave; c < n; c += nw) {
+    const int32_t gc = gen[perm[c]];
+    for (int64_t e = colptr[c] + lane; e < colptr[c + 1]; e += 64) {
+      key[e] = (uint8_t)(gc + gen[perm[prow[e]]]);
+      slot[e] = (uint32_t)e;
+    }
+  }
+}
+
+__global__ void k_ibd_bounds(int64_t nnz, const uint8_t* __restrict__ skey, int64_t* __restrict__ pass_ptr) {
+  // pass_ptr[k] = first position of key k in the sorted key array (entries of absent keys are fixed up on the host)
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nnz) return;
+  if (t == 0 || skey[t] != skey[t - 1]) pass_ptr[skey[t]] = t;
+}
+
+__device__ __forceinline__ double ibd_look(int32_t p, int32_t q, const int64_t* __restrict__ colptr, const int32_t* __restrict__ prow,
+                                           const int32_t* __restrict__ iperm, const double* __restrict__ vals) {
+  if (p < 0 || q < 0) return 0.0;
+  const int32_t P = iperm[p], Q = iperm[q];
+  const int32_t c = min(P, Q), r = max(P, Q);
+  int64_t lo = colptr[c], hi = colptr[c + 1];
+  while (lo < hi) {  // first slot of column c whose row is >= r (rows ascending, diagonal first)
+    const int64_t mid = (lo + hi) >> 1;
+    if (prow[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  return (lo < colptr[c + 1] && prow[lo] == r) ? vals[lo] : 0.0;  // no stored entry: no common ancestor, A = 0
+}
+
+__global__ __launch_bounds__(256) void k_ibd_pass(int64_t cnt, const uint32_t* __restrict__ slots, int32_t n,
+                                                  const int64_t* __restrict__ colptr, const int32_t* __restrict__ prow,
+                                                  const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm,
+                                                  const int32_t* __restrict__ par, double* vals) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt) return;
+  const int64_t e = slots[t];
+  int32_t lo = 0, hi = n;  // column of slot e: last c with colptr[c] <= e
+  while (hi - lo > 1) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (colptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int32_t a = perm[lo], b = perm[prow[e]];
+  const int32_t i = max(a, b), j = min(a, b);
+  const int32_t f = par[2 * i], m = par[2 * i + 1];
+  double v;
+  if (i == j) v = 1.0 + 0.5 * ibd_look(f, m, colptr, prow, iperm, vals);
+  else v = 0.5 * (ibd_look(f, j, colptr, prow, iperm, vals) + ibd_look(m, j, colptr, prow, iperm, vals));
+  vals[e] = v;
+}
+
 }  // namespace scilmm

@@ -54,10 +54,28 @@ class Symbolic(object):
         if upload:
             self.upload_values()
 
-    def upload_values(self):
+    def upload_values(self, skip=()):
         for k in range(self.K):
-            check(lib().scilmm_values_upload(self._h, k, ptr(self._data[k])), self._h)
+            if k not in skip:
+                check(lib().scilmm_values_upload(self._h, k, ptr(self._data[k])), self._h)
         self._uploaded = True
+
+    def ibd_values_from_pedigree(self, k, parents):
+        """Compute matrix k's values -- the IBD (numerator relationship) matrix of the pedigree ``parents`` ((n, 2), -1 =
+        unknown, individuals in the matrices' row order, parents before children) -- ON THE DEVICE, straight into its
+        HBM-resident value slots: they never cross PCIe (``scilmm_ibd_values_device``).  The analysed pattern of matrix k
+        must be the pedigree's common-ancestor pattern (``scilmm_amd.ibd.ibd_pattern_from_parents``)."""
+        par = np.ascontiguousarray(parents, dtype=np.int32)
+        if par.shape != (self.n, 2):
+            raise ValueError("parents must be an (n, 2) table")
+        check(lib().scilmm_ibd_values_device(self._h, k, self.n, ptr(par)), self._h)
+
+    def values_slots(self, k):
+        """Matrix k's device-resident values in pattern-slot order (tests, diagnostics)."""
+        diag_only = self._indices[k].size == self.n and np.array_equal(self._indices[k], np.arange(self.n))
+        out = np.empty(self.n if diag_only else self.info().nnz_pattern)
+        check(lib().scilmm_values_download(self._h, k, ptr(out)), self._h)
+        return out
 
     def set_values(self, k, data):
         """Replace the values of matrix k (same pattern)."""

@@ -28,6 +28,21 @@ def count_ibd_nonzero(par):
     return nnz.value
 
 
+def ibd_pattern_from_parents(par):
+    """The PATTERN of A (pairs with a common ancestor; both triangles, sorted) as a CSR matrix of ones -- no values are
+    computed: they can be produced on the device (``Symbolic.ibd_values_from_pedigree``)."""
+    par = _parents32(par)
+    n = par.shape[0]
+    h, nnz = C.c_void_p(), C.c_int64(0)
+    check(lib().scilmm_ibd_build(n, ptr(par), 2, C.byref(h), C.byref(nnz)))
+    try:
+        ap, ai = np.empty(n + 1, np.int64), np.empty(nnz.value, np.int32)
+        check(lib().scilmm_ibd_export(h, ptr(ap), ptr(ai), None, None, None, None, None, None))
+    finally:
+        lib().scilmm_ibd_free(h)
+    return sp.csr_matrix((np.ones(nnz.value), ai, ap), shape=(n, n))
+
+
 def ibd_from_parents(par, return_LD=False):
     """A = L D L^T (symmetric CSR, sorted); optionally also L (CSR) and D (vector)."""
     par = _parents32(par)

@@ -471,3 +471,111 @@ def test_100k_config_against_cpu_port(monkeypatch, env):
     assert abs(nll - nll_o) < 1e-10 * abs(nll_o)
     assert np.abs(grad - grad_o).max() < 1e-7 * np.abs(grad_o).max()
     chol.release_factors()
+
+
+def test_k3_additive_dominance_fp32_fronts_100k(monkeypatch):
+    """BASELINE configs[4]'s model AND arithmetic at the largest size a CPU check reaches: 100k individuals, K = 3
+    (additive A + dominance D built by the device kernel + identity; reference Estimation/LMM.py:154-169,
+    Matrices/Dominance.py:12-43), fp64 factor with fp32 MFMA fronts.
+      * the all-fp64 factor of V = 0.3 A + 0.1 D + 0.6 I equals the BLAS-3 CPU port's (log-det, 5-column solve: 1e-10);
+      * the fp32-front factor agrees with it to 1e-5 (entries of L), 1e-7 (log-det), and its REFINED solves to 1e-10."""
+    from oracle import oracle as O
+    from scilmm_amd.harness.pedigree import make_problem
+    monkeypatch.setenv("SCILMM_TUNING", "1")
+    monkeypatch.setenv("SCILMM_DENSE", "1")  # the 100k tail (16k columns) is narrower than the automatic threshold
+    mats, C, y = make_problem(100000, 0.005, seed=0, with_dominance="device")
+    A, D = mats
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    assert np.all(D.diagonal() == 1.0) and abs(D - D.T).max() == 0.0 and 0.0 < D.nnz < A.nnz + 1
+    s2 = [0.3, 0.1, 0.6]
+    V = (s2[0] * A + s2[1] * D + s2[2] * I).tocsr()
+    sym = _engine([A, D, I])
+    f = sym.factorize(s2)
+    o = O.CPUPortFactor(sym.arrays(), sym.get("pat_colptr"), V)
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, 5))
+    Xo = o(B)
+    assert abs(f.logdet() - o.logdet()) < TOL * abs(o.logdet())
+    assert rel_err(f(B), Xo) < TOL
+    ld64, L64 = f.logdet(), f.L().data.copy()
+    del f, o
+    sym.set_front_precision(32)
+    f32 = sym.factorize(s2)
+    L32 = f32.L().data
+    errL = np.abs(L32 - L64).max() / np.abs(L64).max()
+    assert 0.0 < errL < 1e-5, errL
+    assert abs(f32.logdet() - ld64) < 1e-7 * abs(ld64)
+    assert rel_err(f32(B), Xo) < TOL                       # two refinement sweeps against the exact V (fp64 SpMM)
+    assert rel_err(V @ f32(B), B) < 1e-11
+
+
+def test_lmm_k3_evaluation_matches_oracle_20k():
+    """One likelihood + gradient evaluation of the reference's second entry point, `Estimation.LMM` (LMM.py:75-110), with
+    K = 3 (A + device-built D + I) on a 20k pedigree, against `reml_oracle.evaluate` on the simplicial C oracle with the
+    same permutation and the same np.random stream: nll 1e-10, gradient 1e-7."""
+    import importlib
+    from oracle import reml_oracle as RO
+    from scilmm_amd.harness.pedigree import make_problem
+    LM = importlib.import_module("scilmm_amd.Estimation.LMM")
+    mats, C, y = make_problem(20000, 0.01, seed=1, with_dominance="device")
+    n = mats[0].shape[0]
+    K3 = list(mats) + [sp.identity(n, format="csr")]
+    Cf = np.hstack([np.ones((n, 1)), C[:, :1]])      # LMM prepends the intercept (LMM.py:156-157)
+    chol = LM.SparseCholesky()
+    x = np.log([0.3, 0.1, 0.6])
+    np.random.seed(9)
+    nll, grad = LM.bolt_gradient_estimation(x, chol, K3, Cf, y, True, 30, False)
+    perm = chol.engine_for(K3).P()
+    np.random.seed(9)
+    nll_o, grad_o = RO.evaluate(x, K3, Cf, y, True, 30, perm=perm)
+    assert abs(nll - nll_o) < 1e-10 * abs(nll_o)
+    assert np.abs(grad - grad_o).max() < 1e-7 * np.abs(grad_o).max()
+    chol.release_factors()
+
+
+def test_ibd_values_built_on_the_device_match_reference_goldens_bit_for_bit():
+    """the IBD (numerator relationship) VALUES computed on the device straight into the engine's value slots
+    (`scilmm_ibd_values_device`: tabular recursion, one launch per generation sum) -- never on the host, never over PCIe.
+    Bit-exact (dyadic rationals) against the matrices the REFERENCE's own Numerator.LD + create_numerator produced
+    (goldens G0: relationship_example.csv, G1: 2000-individual simulated pedigree), against the host builder on a 100k
+    pedigree, and the factor built from them equals the factor built from uploaded values."""
+    import os
+    from scilmm_amd import ibd
+    from scilmm_amd.Matrices.Dominance import parents_of
+    from scilmm_amd.harness import pedigree as H
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g0 = np.load(os.path.join(gold, "G0_relationship_example.npz"), allow_pickle=True)
+    g1 = np.load(os.path.join(gold, "G1_reml_2000.npz"))
+    g2 = np.load(os.path.join(gold, "G2_lmm_dominance.npz"))
+    shape = tuple(g1["A_shape"])
+    A1 = sp.csr_matrix((g1["A_data"], g1["A_indices"], g1["A_indptr"]), shape=shape)
+    par1 = parents_of(sp.csr_matrix((g2["rel_data"], g2["rel_indices"], g2["rel_indptr"]), shape=shape))
+    cases = [(sp.csr_matrix(g0["A"]), parents_of(sp.csr_matrix(g0["rel"]))), (A1, par1)]
+    parL, _, _ = H.simulate_pedigree(100000, 0.005, seed=0)
+    cases.append((None, parL))
+    for Aref, par in cases:
+        P = ibd.ibd_pattern_from_parents(par)            # pattern only: no value exists on the host
+        if Aref is None:
+            Aref = ibd.ibd_from_parents(par)              # (host builder: itself equal to the reference on the goldens)
+        Aref = Aref.tocsr()
+        Aref.sort_indices()
+        assert np.array_equal(P.indices, Aref.indices) and np.array_equal(P.indptr, Aref.indptr)
+        n = P.shape[0]
+        I = sp.identity(n, format="csr")
+        sym = _engine([P, I], upload=False)
+        sym.upload_values(skip=(0,))
+        sym.ibd_values_from_pedigree(0, par)
+        perm, colptr, prow = sym.get("perm"), sym.get("pat_colptr"), sym.get("pat_row")
+        got = sp.csc_matrix((sym.values_slots(0), prow, colptr), shape=(n, n))          # tril(A[P][:,P]), permuted labels
+        want = sp.tril(Aref[perm][:, perm]).tocsc()
+        want.sort_indices()
+        got.sort_indices()
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert np.array_equal(got.data, want.data), np.abs(got.data - want.data).max()
+        if n <= 2000:
+            f = sym.factorize([0.4, 0.6])
+            ref = _engine([Aref, I]).factorize([0.4, 0.6])
+            assert f.logdet() == ref.logdet()
+    with pytest.raises(Exception):
+        sym.ibd_values_from_pedigree(0, par[::-1].copy())   # not in pedigree order
