@@ -390,13 +390,88 @@ def estimate_var_comps(cholesky_func, mats, covariates, y, reml=True, sim_num=10
         x0 = np.ones((len(mats)))
     x0 = x0 / x0.sum()
     if aireml:
-        raise NotImplementedError('AI-REML is broken')
+        return _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose)
     optObj = optimize.minimize(bolt_gradient_estimation, np.log(x0),
                                args=(cholesky_func, mats, covariates, y, reml, sim_num, verbose, True),
                                jac=True, method='L-BFGS-B', options={'eps': 1e-5, 'ftol': 1e-7})
     if not optObj.success:
         print('optimization failed with message: %s' % optObj.message)
     return np.exp(optObj.x)
+
+
+def _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose, max_iter=50, tol=1e-8, ftol=1e-7):
+    """Average-information REML: the branch the reference leaves as a stub (``raise NotImplementedError('AI-REML is
+    broken')``, SparseCholesky.py:128-130).  Newton-type iteration on sigma2 itself,
+        sigma2 <- sigma2 - AI^-1 g,      g_k  = d nll / d sigma2_k      (the estimator of compute_gradients, :62-74),
+                                         AI_kl = 1/2 y' P A_k P A_l P y  (average of observed and expected information),
+    with P y = V^-1 (y - C beta).  The gradient comes from ONE call of ``bolt_gradient_estimation`` (take_exp=False): the
+    same factorization, fused sweep and Monte-Carlo -- or, with ``SparseCholesky(exact_trace=True)``, exact -- trace as the
+    L-BFGS-B path; the AI matrix costs K more single-column solves on the factor that evaluation left resident.  Steps are
+    halved until every component stays positive and the likelihood does not rise.  The Monte-Carlo trace uses COMMON
+    random numbers: every evaluation of the fit restarts np.random from the state it had on entry (the probe vectors
+    are the same at every sigma2, as in BOLT-REML), so the objective is one smooth function and the iteration converges
+    like a Newton method instead of wandering inside the estimator's noise; on return the stream has advanced by one
+    evaluation.  Stops on the reference's L-BFGS-B tolerance (relative likelihood change <= 1e-7) or a relative step
+    below ``tol``.  Opt-in: ``REML(..., aireml=True)``; the default optimiser stays the reference's L-BFGS-B."""
+    s2 = np.asarray(x0, dtype=float).copy()
+    rng_state = np.random.get_state()
+
+    def evaluate(v):
+        np.random.set_state(rng_state)
+        nll, grad = bolt_gradient_estimation(v, cholesky_func, mats, covariates, y, reml, sim_num, False, take_exp=False)
+        if _is_hip(cholesky_func):
+            fac = cholesky_func._factor_state[id(cholesky_func.engine_for(mats))]
+        else:
+            fac = cholesky_func(matrices_weighted_sum(mats, v))
+        # P y and P A_k P y through the resident factor: 1 + K multi-column solves
+        ViC = fac(covariates)
+        G = la.cho_factor(covariates.T.dot(ViC))
+
+        def proj(Z):
+            ViZ = fac(Z)
+            return ViZ - ViC.dot(la.cho_solve(G, covariates.T.dot(ViZ)))
+
+        Py = proj(y)
+        APy = np.stack([m.dot(Py) for m in mats], axis=1)          # n x K
+        PAPy = proj(APy)
+        AI = 0.5 * APy.T.dot(PAPy)
+        return nll, grad, 0.5 * (AI + AI.T)
+
+    def decrement(g, M):
+        # Newton decrement g' AI^-1 g: the size of the gradient in the metric of the information matrix
+        try:
+            return float(g.dot(la.solve(M, g, assume_a='pos')))
+        except la.LinAlgError:
+            return float(g.dot(g / np.maximum(np.diag(M), 1e-300)))
+
+    nll, grad, AI = evaluate(s2)
+    for it in range(max_iter):
+        try:
+            step = -la.solve(AI, grad, assume_a='pos')
+        except la.LinAlgError:
+            step = -grad / np.maximum(np.diag(AI), 1e-300)
+        lam = decrement(grad, AI)
+        t = 1.0
+        accepted = False
+        for halving in range(12):
+            cand = s2 + t * step
+            if np.all(cand > 1e-10 * s2.sum()):
+                nll_c, grad_c, AI_c = evaluate(cand)
+                # the estimator's gradient is not exactly the derivative of its likelihood value (exact log-det, estimated
+                # trace): a step counts as progress when either of them says so
+                if nll_c <= nll + 1e-12 * abs(nll) or decrement(grad_c, AI_c) < lam:
+                    accepted = True
+                    break
+            t *= 0.5
+        if verbose:
+            print('AI-REML iteration %d: sigma2 %s nll %.10e step %.3g' % (it, cand if accepted else s2, nll_c if accepted else nll, t))
+        if not accepted:
+            break
+        done = np.abs(cand - s2).max() <= tol * np.abs(s2).max() or abs(nll - nll_c) <= ftol * max(abs(nll), abs(nll_c), 1.0)
+        s2, nll, grad, AI = cand, nll_c, grad_c, AI_c
+        if done:
+            break
+    return s2
 
 
 def _final_factor(cholesky_func, mats, coefficients):
@@ -439,11 +514,12 @@ def compute_varcomp_stderr(mats, covariates, factor, y, sim_num):
     return np.sqrt(np.diag(la.inv(-hess)) * (1 + 1.0 / sim_num))
 
 
-def REML(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=False):
-    """REML fit (SparseCholesky.py:177-189). Returns the reference's dict of three arrays."""
+def REML(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=False, aireml=False):
+    """REML fit (SparseCholesky.py:177-189). Returns the reference's dict of three arrays.  ``aireml=True`` (not in the
+    reference's signature, whose AI-REML branch is a stub) selects the average-information iteration instead of L-BFGS-B."""
     y = y / y.std()
     mats = list(mats) + [sparse.eye(y.shape[0]).tocsr()]
-    varcomp_estimates = estimate_var_comps(cholesky_func, mats, covariates, y, reml, sim_num, verbose)
+    varcomp_estimates = estimate_var_comps(cholesky_func, mats, covariates, y, reml, sim_num, verbose, aireml=aireml)
     factor = _final_factor(cholesky_func, mats, varcomp_estimates)
     _, _, _, fixed_effects = estimate_fixed_effects(factor, y, covariates)
     sigmas_sigmas = compute_varcomp_stderr(mats, covariates, factor, y, sim_num)
