@@ -297,8 +297,17 @@ def main():
         sym = Symbolic([A] + (comps or []) + [sp.identity(n, format="csr")], **sym_opts)
     else:
         from scilmm_amd.dist import HipChainEngine
-        eng = HipChainEngine([A, sp.identity(n, format="csr")], rank, world, dist, dev)
+        # one analysis per NODE: rank 0 analyses the pattern and leaves its image in /dev/shm, the others load it
+        cache = "/dev/shm/scilmm_bench_sym_%s" % os.environ.get("MASTER_PORT", "0")
+        if rank == 0:
+            Symbolic([A, sp.identity(n, format="csr")], upload=False, cache=cache)
+        dist.barrier()
+        eng = HipChainEngine([A, sp.identity(n, format="csr")], rank, world, dist, dev, cache=cache)
         sym = eng.sym
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            shutil.rmtree(cache, ignore_errors=True)
     t_sym = time.time() - t0
     info = sym.info()
     sym.set_profiling(True)

@@ -87,6 +87,13 @@ int scilmm_symbolic_info(const scilmm_symbolic* sym, scilmm_info* info);
 int scilmm_symbolic_get(const scilmm_symbolic* sym, const char* what, void* out, int64_t* count);
 const char* scilmm_symbolic_error(const scilmm_symbolic* sym);
 void scilmm_symbolic_free(scilmm_symbolic* sym);
+/* Image of an analysis on disk or in /dev/shm (the reference keeps its stage artefacts as files,
+ * scilmm/IBDCompute.py:82-84): the 20 s analysis of the 1M config is done once per pattern and NODE instead of once per
+ * process (8 ranks of a multi-GPU run, repeated fits).  `key` = the caller's 64-bit hash of everything the analysis
+ * depends on (patterns, permutation, options); scilmm_symbolic_load returns SCILMM_ERR_STATE unless the file exists, was
+ * written by this build and carries that key -- the caller then analyses afresh.  Host only. */
+int scilmm_symbolic_save(const scilmm_symbolic* sym, const char* path, uint64_t key);
+int scilmm_symbolic_load(const char* path, uint64_t key, scilmm_symbolic** out);
 
 /* The ordering step of cholmod_analyze alone (SparseCholesky.py:17 ordering_method): fill-reducing permutation of a
  * symmetric CSR pattern (only entries with column < row are read).  method 0 = approximate minimum degree,

@@ -56,7 +56,7 @@ class SparseCholesky(object):
     """
 
     def __init__(self, use_long=False, mode='supernodal', ordering_method='default', perm=None, fused=True,
-                 exact_trace=False):
+                 exact_trace=False, cache_dir=None, metrics=None):
         _lib.lib()  # fail loudly when the HIP library is not built
         self._use_long = use_long
         self._mode = mode
@@ -67,6 +67,13 @@ class SparseCholesky(object):
         # Monte-Carlo estimate (SparseCholesky.py:49-52, :65) -- see _exact_traces.  Default off: the default
         # behaviour has to be the reference's stochastic estimator.
         self.exact_trace = exact_trace
+        # cache_dir: keep the image of the symbolic analysis there (once per pattern instead of once per process; the
+        # reference writes its stage artefacts to files as well, scilmm/IBDCompute.py:82-84); also SCILMM_SYMBOLIC_CACHE.
+        self.cache_dir = cache_dir
+        # metrics: path of a JSON-lines file (also SCILMM_METRICS) that receives one record per likelihood evaluation --
+        # sigma2, nll, gradient, and the device timers of that evaluation
+        self.metrics = metrics or os.environ.get("SCILMM_METRICS")
+        self._n_eval = 0
         self._cache = {}
 
     def _ordering(self):
@@ -109,7 +116,7 @@ class SparseCholesky(object):
         key = _pattern_key(mats)
         hit = self._cache.get(key)
         if hit is None:
-            sym = Symbolic(mats, perm=self._perm, ordering=self._ordering())
+            sym = Symbolic(mats, perm=self._perm, ordering=self._ordering(), cache=self.cache_dir)
             self._cache = {key: (sym, [m.data.copy() for m in mats])}
         else:
             sym, datas = hit
@@ -350,6 +357,22 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
     return nll, grad, fac
 
 
+def _write_metrics(cholesky_func, mats, sig2g_array, nll, grad, seconds, reml, sim_num):
+    """One JSON line per likelihood evaluation: what was evaluated, what came out, where the time went
+    (HIP-event timers of this evaluation's assembly / factorization / sweeps / L*R / quadratic forms)."""
+    import json
+    sym = cholesky_func.engine_for(mats)
+    info = sym.info()
+    cholesky_func._n_eval += 1
+    rec = {"evaluation": cholesky_func._n_eval, "time": time.time(), "n": int(info.n), "K": int(info.K), "nnzL": int(info.nnzL),
+           "factor_flops": info.flops, "reml": bool(reml), "sim_num": int(sim_num), "sigma2": np.asarray(sig2g_array).tolist(),
+           "nll": float(nll), "grad_sigma2": np.asarray(grad).tolist(), "seconds": seconds,
+           "device_ms": {k: v for k, v in sym.timing().items() if k.endswith("_ms")},
+           "launches": int(sym.timing()["n_launches"]), "symbolic_from_cache": bool(getattr(sym, "from_cache", False))}
+    with open(cholesky_func.metrics, "a") as fh:
+        fh.write(json.dumps(rec) + "\n")
+
+
 def bolt_gradient_estimation(log_sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num, verbose,
                              take_exp=True):
     """nll and d nll / d log(sigma2) at one point (SparseCholesky.py:77-117)."""
@@ -358,7 +381,10 @@ def bolt_gradient_estimation(log_sig2g_array, cholesky_func, mats, covariates, y
         t0 = time.time()
         print('estimating nll and its gradient at:', sig2g_array)
     if _is_hip(cholesky_func):
+        t_eval = time.time()
         nll, grad, _ = _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num)
+        if cholesky_func.metrics:
+            _write_metrics(cholesky_func, mats, sig2g_array, nll, grad, time.time() - t_eval, reml, sim_num)
     else:
         V = matrices_weighted_sum(mats, sig2g_array)
         n = V.shape[0]

@@ -44,6 +44,22 @@ int scilmm_symbolic_create(int32_t n, int32_t K, const int64_t* const* indptr, c
   return SCILMM_OK;
 }
 
+int scilmm_symbolic_save(const scilmm_symbolic* h, const char* path, uint64_t key) {
+  if (!h || !h->S || !path) return SCILMM_ERR_ARG;
+  return scilmm::symbolic_save(*h->S, path, key) ? SCILMM_OK : SCILMM_ERR_STATE;
+}
+
+int scilmm_symbolic_load(const char* path, uint64_t key, scilmm_symbolic** out) {
+  scilmm::use_host_threads();
+  if (!path || !out) return SCILMM_ERR_ARG;
+  scilmm::Symbolic* S = scilmm::symbolic_load(path, key);
+  if (!S) return SCILMM_ERR_STATE;  // no file, another key / build, or a damaged image: the caller analyses afresh
+  scilmm_symbolic* h = new scilmm_symbolic();
+  h->S = S;
+  *out = h;
+  return SCILMM_OK;
+}
+
 int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
   if (!h || !h->S || !info) return SCILMM_ERR_ARG;
   const Symbolic& S = *h->S;

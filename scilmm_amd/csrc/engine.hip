@@ -1696,7 +1696,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   }
   const bool dist = D->world > 1 && D->dist_first < S.nsuper;
   const size_t sm_upd = sizeof(double) * (size_t)(2 * KC * LDA + 2 * KC * LDB) + sizeof(int32_t) * TM;
-  const size_t sm_potrf = sizeof(double) * (size_t)((NB / 2) * (NB + 1) + NJB * 16 * 17);
+  const size_t sm_potrf = sizeof(double) * (size_t)((NB / 2) * (NB + 1) + NJB * 16 * 17 + 32);
   hipStream_t st = D->stream;
   int64_t launches = 0;
   HIPCHK(hipEventRecord(D->ev[0], st));
@@ -1862,20 +1862,23 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], D->dwork_l_ptr[l + 1] - D->dwork_l_ptr[l], sh);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 11], st));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
-    launch_reduce(st, D->d_red_tiles + D->red_ptr[l], D->red_ptr[l + 1] - D->red_ptr[l], D->d_tile_pslot, D->d_tile_pnseg, (const double*)sh);
+    // (the late slabs are folded by k_potrf / k_trsm on load: no k_reduce launch on the main stream's chain)
     launch_cells(st, 1, l);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 2], st));
     if (f1 > f0) {
       hipLaunchKernelGGL(k_potrf, dim3((unsigned)(f1 - f0)), dim3(256), sm_potrf, st, D->v, D->d_level_fronts + f0, fac->L,
-                         fac->invD, fac->logd, fac->status);
+                         fac->invD, fac->logd, fac->status, (const int32_t*)D->d_tile_pslot, (const int32_t*)D->d_tile_pnseg,
+                         (const double*)sh);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
     if (t1 > t0) {
       if (D->use_mfma)
-        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD);
+        hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD,
+                           (const int32_t*)D->d_tile_pslot, (const int32_t*)D->d_tile_pnseg, (const double*)sh);
       else
-        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD);
+        hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD,
+                           (const int32_t*)D->d_tile_pslot, (const int32_t*)D->d_tile_pnseg, (const double*)sh);
       launches++;
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));

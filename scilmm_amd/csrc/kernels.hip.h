@@ -1028,9 +1028,13 @@ __device__ unsigned long long g_potrf_prof[16];
 #else
 #define PPROF(i) do {} while (0)
 #endif
+// (round 3) The split-K partial slabs of the level's LATE update are folded in HERE, on load, and in k_trsm -- not by a
+// k_reduce launch in between: one launch and one round trip of the panel less on the per-level chain of the main stream
+// (104 us of 430 us per level at the 100k config).  A tile's slabs are summed in slab order: fixed, reproducible.
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                double* __restrict__ invD, double* __restrict__ logd,
-                                               int32_t* __restrict__ status) {
+                                               int32_t* __restrict__ status, const int32_t* __restrict__ tile_pslot,
+                                               const int32_t* __restrict__ tile_pnseg, const double* __restrict__ slabs) {
   // LDS budget: the look-ahead keeps two 74 KB update workgroups resident on every CU, so a kernel of the main
   // stream can only start where ONE of them has retired: <= 85 KB.  Only the lower triangle of L is kept, folded
   // into NB/2 rows of NB+1 doubles (row i >= NB/2 holds L[i][0..i]; the rest of that row holds row NB-1-i), plus
@@ -1039,6 +1043,7 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* F = smem;                 // [HB][LDF] folded lower triangle
   double* Xd = smem + HB * LDF;     // [NJB][16][17]  Xd[kb][n][k] = X(16 kb + n, 16 kb + k), zero above the diagonal
+  double* piv = Xd + NJB * XS;      // [32] pivot column of L / pivot row of X of the diagonal-block step in flight (wave 0)
 #define FA(i, k) (((i) >= HB) ? ((i) - HB) * LDF + (k) : (HB - 1 - (i)) * LDF + (NB - (i)) + (k))
   __builtin_amdgcn_s_setprio(3);  // latency chain of the main stream: issue ahead of the co-resident update waves
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1048,6 +1053,10 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   double* P = L + S.sn_loff[s];
   double* I = invD + S.inv_off[s];
   const int nb = (w + 15) >> 4, W = nb << 4;  // padded with an identity block
+  // late partial slabs of the front's first tile (it holds the whole diagonal block)
+  const int64_t g0 = S.tile_base[s];
+  const int32_t pn = tile_pnseg[g0];
+  const double* sl0 = slabs + (int64_t)tile_pslot[g0] * (TM * NB);
 #ifdef SCILMM_POTRF_PROF
   unsigned long long tprev_ = wall_clock64();
   if (w == NB && tid == 0) atomicAdd(&g_potrf_prof[15], 1ull);
@@ -1065,6 +1074,15 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
         const int k = idx / NB, i = idx % NB;
         v[u] = P[(int64_t)k * m + max(i, k)];  // clamped into the lower triangle: unconditional loads
       }
+      for (int sg = 0; sg < pn; ++sg) {
+        const double* q = sl0 + (int64_t)sg * (TM * NB);
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+          const int idx = tid + 256 * (u + PT * hpass);
+          const int k = idx / NB, i = idx % NB;
+          v[u] -= q[k * TM + max(i, k)];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < PT; ++u) {
         const int idx = tid + 256 * (u + PT * hpass);
@@ -1080,7 +1098,10 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
         const int idx = base + 256 * u;
         const int k = idx / W, i = idx - k * W;
         v[u] = (i == k) ? 1.0 : 0.0;
-        if (idx < W * W && i < w && k < w && i >= k) v[u] = P[(int64_t)k * m + i];
+        if (idx < W * W && i < w && k < w && i >= k) {
+          v[u] = P[(int64_t)k * m + i];
+          for (int sg = 0; sg < pn; ++sg) v[u] -= sl0[(int64_t)sg * (TM * NB) + k * TM + i];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1099,43 +1120,61 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
   auto diag16 = [&](int kb) {
     const int o = kb << 4;
     double* Xk = Xd + kb * XS;
-    // ---- 16 x 16 diagonal block in registers, right-looking: lane r (mod 16) owns row r of L; the pivot
-    //      column is broadcast with v_readlane (scalar operands), so a step is one rsqrt + independent FMAs
-    const int r = lane & 15;
-    double a[16], x[16];
+    // ---- 16 x 16 diagonal block (factor + inverse), right-looking, on ALL 64 lanes of the wave: lane (r, q) = (lane & 15,
+    //      lane >> 4) holds A(r, c) and X(c, r) for the four columns / rows c = q + 4 t.  Step j: the quarter that holds
+    //      column j publishes it (and row j of X) through 32 doubles of LDS -- one write -> read round trip per step --
+    //      and every lane scales and applies it to its own four entries.  (Round 2 kept a whole row per lane on 16 lanes
+    //      and broadcast the pivot column with 2 x 15 v_readlane per step: 1300 readlanes, SGPR spills through
+    //      v_writelane, 10 us per block -- 80 of the kernel's 113 us; profiles/r3_potrf_phases.txt.)  Same products and
+    //      sums per entry as before: the factor's bits do not change.
+    const int r = lane & 15, q = lane >> 4;
+    double a[4], x[4];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      a[c] = (c <= r) ? F[FA(o + r, o + c)] : 0.0;
-      x[c] = (c == r) ? 1.0 : 0.0;
+    for (int t = 0; t < 4; ++t) {
+      const int c = q + 4 * t;
+      a[t] = (c <= r) ? F[FA(o + r, o + c)] : 0.0;
+      x[t] = (c == r) ? 1.0 : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      double dj = bc_lane(a[j], j);
+      const int qj = j & 3, tj = j >> 2;
+      if (q == qj) {
+        piv[r] = a[tj];        // A(r, j): the pivot column before scaling (rows r < j: don't-care)
+        piv[16 + r] = x[tj];   // X(j, r) before scaling
+      }
+      __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations execute in order; this only pins the code order)
+      double dj = piv[j];
       if (!(dj > 0.0) || !(dj < 1.0e300)) {
         if (lane == 0) atomicMin(status, c0 + o + j);
         dj = 1.0;
       }
       double y = rsqrt(dj);
       y = y * (1.5 - 0.5 * dj * y * y);  // one Newton step: full double precision
-      const double lj = (r >= j) ? a[j] * y : 0.0;  // L(r, j); the diagonal comes out as dj / sqrt(dj)
-      a[j] = lj;
-      // inverse of the block by forward substitution, right-looking, INTERLEAVED with the factorization (column
-      // j of L is final here): lane r owns COLUMN r of X = L^-1; two independent dependency chains per step
-      x[j] *= y;  // rows above the diagonal stay exactly zero
+      const double lr = (r >= j) ? piv[r] * y : 0.0;  // L(r, j); the diagonal comes out as dj / sqrt(dj)
+      const double xj = piv[16 + r] * y;              // X(j, r), final (zero above the diagonal: r > j)
+      double lc[4];
 #pragma unroll
-      for (int c = j + 1; c < 16; ++c) {
-        const double lcj = bc_lane(lj, c);  // L(c, j)
-        a[c] -= lj * lcj;                   // A(r,c) -= L(r,j) L(c,j)  (used for r >= c)
-        x[c] -= lcj * x[j];
+      for (int t = 0; t < 4; ++t) lc[t] = piv[q + 4 * t] * y;  // L(c, j) of this lane's columns
+      __builtin_amdgcn_wave_barrier();
+      if (q == qj) {
+        a[tj] = lr;
+        x[tj] = xj;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = q + 4 * t;
+        if (c > j) {
+          a[t] -= lr * lc[t];   // A(r,c) -= L(r,j) L(c,j)  (used for r >= c)
+          x[t] -= lc[t] * xj;   // X(c,r) -= L(c,j) X(j,r)
+        }
       }
     }
-    if (lane < 16) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        if (c <= r) F[FA(o + r, o + c)] = a[c];  // L(o+r, o+c)
-        Xk[c * 17 + r] = x[c];                   // X(o+c, o+r); zero for c < r
-        if (c >= r && o + c < w && o + r < w) I[(int64_t)(o + r) * w + o + c] = x[c];
-      }
+    for (int t = 0; t < 4; ++t) {
+      const int c = q + 4 * t;
+      if (c <= r) F[FA(o + r, o + c)] = a[t];  // L(o+r, o+c)
+      Xk[c * 17 + r] = x[t];                   // X(o+c, o+r); zero for c < r
+      if (c >= r && o + c < w && o + r < w) I[(int64_t)(o + r) * w + o + c] = x[t];
     }
   };
   auto pair_update = [&](int o, int ib, int kk) {
@@ -1252,7 +1291,8 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int32_t* __restri
 //   P[i, :] <- P[i, :] * invL^T   for the rows i >= w of a 128-row tile.   D[M=j][N=i].
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
-                                              const double* __restrict__ invD) {
+                                              const double* __restrict__ invD, const int32_t* __restrict__ tile_pslot,
+                                              const int32_t* __restrict__ tile_pnseg, const double* __restrict__ slabs) {
   __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
   __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
   __builtin_amdgcn_s_setprio(3);
@@ -1282,10 +1322,18 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
   const double* pa = P + R0 + (ha ? t : 0);
   const double* pb = I + (hb ? q : 0);
   double ra[PA], rb[PB];
+  // late partial slabs of this tile (folded here instead of by a k_reduce launch: see k_potrf)
+  const int32_t pn = tile_pnseg[g];
+  const double* sl = slabs + (int64_t)tile_pslot[g] * (TM * NB) + (ha ? t : 0);
   auto fetch = [&](int k0) {
     const int kc = min(KCS, w - k0);
 #pragma unroll
     for (int i = 0; i < PA; ++i) ra[i] = pa[(int64_t)(k0 + min(ka + 2 * i, kc - 1)) * m];
+    for (int sg = 0; sg < pn; ++sg) {
+      const double* q = sl + (int64_t)sg * (TM * NB);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] -= q[(k0 + min(ka + 2 * i, kc - 1)) * TM];
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i) rb[i] = pb[(int64_t)(k0 + min(kb + (256 / NB) * i, kc - 1)) * w];
   };

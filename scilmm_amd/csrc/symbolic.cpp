@@ -1249,4 +1249,91 @@ void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense, 
   S->combos_built = true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-disk / shared-memory image of an analysis (the reference keeps its stage artefacts on disk,
+// scilmm/IBDCompute.py:82-84; here the 20 s analysis of the 1M config need not be redone by every process of a node).
+// Plain binary: a header, then every member of Symbolic in the order of the list below -- which is the single place that
+// names them, for writing and for reading.  The tile combos (built lazily per rank) are not part of the image.
+namespace {
+constexpr uint64_t kImageMagic = 0x53434c4d53594d33ull;  // "SCLMSYM3"
+
+struct ImageIO {
+  FILE* fp;
+  bool write;
+  bool ok = true;
+  template <typename T>
+  void pod(T& v) {
+    if (!ok) return;
+    ok = write ? fwrite(&v, sizeof(T), 1, fp) == 1 : fread(&v, sizeof(T), 1, fp) == 1;
+  }
+  template <typename T>
+  void vec(std::vector<T>& v) {
+    uint64_t cnt = (uint64_t)v.size();
+    pod(cnt);
+    if (!ok) return;
+    if (!write) {
+      if (cnt > ((uint64_t)1 << 40) / sizeof(T)) { ok = false; return; }
+      v.resize((size_t)cnt);
+    }
+    if (cnt) ok = write ? fwrite(v.data(), sizeof(T), (size_t)cnt, fp) == cnt : fread(v.data(), sizeof(T), (size_t)cnt, fp) == cnt;
+  }
+  template <typename T>
+  void vecvec(std::vector<std::vector<T>>& v) {
+    uint64_t cnt = (uint64_t)v.size();
+    pod(cnt);
+    if (!ok) return;
+    if (!write) v.resize((size_t)cnt);
+    for (auto& x : v) vec(x);
+  }
+};
+
+void image_fields(ImageIO& io, Symbolic& S) {
+  io.pod(S.n); io.pod(S.K); io.pod(S.nsuper); io.pod(S.dense_first); io.pod(S.tile_rows); io.pod(S.nlevels);
+  io.pod(S.nnz_pattern); io.pod(S.nnzL); io.pod(S.nnzL_stored); io.pod(S.flops); io.pod(S.update_flops);
+  io.pod(S.dense_flops); io.pod(S.update_flops_pad);
+  io.vec(S.perm); io.vec(S.iperm); io.vec(S.parent); io.vec(S.colcount); io.vec(S.sn_start); io.vec(S.sn_parent);
+  io.vec(S.sn_rowptr); io.vec(S.sn_rows); io.vec(S.sn_loff); io.vec(S.sn_level); io.vec(S.child_ptr); io.vec(S.child_idx);
+  io.vec(S.upd_ptr); io.vec(S.upd_src); io.vec(S.upd_p0); io.vec(S.upd_p1); io.vec(S.upd_jp0);
+  io.vec(S.tile_base); io.vec(S.tile_front);
+  io.vec(S.level_tile_ptr); io.vec(S.level_tiles); io.vec(S.level_pair_ptr); io.vec(S.level_pairs);
+  io.vec(S.level_ptr); io.vec(S.level_fronts);
+  io.vec(S.asm_dst); io.vec(S.diag_dst); io.vec(S.pat_colptr); io.vec(S.pat_row); io.vec(S.inv_off);
+  io.vec(S.tail_blk_ptr); io.vec(S.tail_blk);
+  io.vecvec(S.val_slot); io.vecvec(S.val_src); io.vec(S.is_diag);
+}
+}  // namespace
+
+bool symbolic_save(const Symbolic& S, const char* path, uint64_t key) {
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* fp = fopen(tmp.c_str(), "wb");
+  if (!fp) return false;
+  ImageIO io{fp, true};
+  uint64_t magic = kImageMagic, k = key, nb = (uint64_t)SCILMM_NB;
+  io.pod(magic); io.pod(k); io.pod(nb);
+  image_fields(io, const_cast<Symbolic&>(S));
+  const bool ok = io.ok && fclose(fp) == 0;
+  if (!ok) { remove(tmp.c_str()); return false; }
+  return rename(tmp.c_str(), path) == 0;  // readers never see a half-written image
+}
+
+Symbolic* symbolic_load(const char* path, uint64_t key) {
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return nullptr;
+  ImageIO io{fp, false};
+  uint64_t magic = 0, k = 0, nb = 0;
+  io.pod(magic); io.pod(k); io.pod(nb);
+  if (!io.ok || magic != kImageMagic || k != key || nb != (uint64_t)SCILMM_NB) { fclose(fp); return nullptr; }
+  Symbolic* S = new Symbolic();
+  image_fields(io, *S);
+  fclose(fp);
+  // structural sanity: sizes must agree with the header fields
+  const bool sane = io.ok && S->n >= 0 && (int64_t)S->perm.size() == S->n && (int64_t)S->sn_start.size() == (int64_t)S->nsuper + 1 &&
+                    (int64_t)S->sn_loff.size() >= S->nsuper && (int64_t)S->asm_dst.size() == S->nnz_pattern &&
+                    (int64_t)S->val_slot.size() == S->K && (int64_t)S->level_ptr.size() == (int64_t)S->nlevels + 1;
+  if (!sane) { delete S; return nullptr; }
+  S->combos_built = false;
+  // (tile combo arrays of a fresh analysis are sized by build_tile_combos on demand)
+  return S;
+}
+
 }  // namespace scilmm

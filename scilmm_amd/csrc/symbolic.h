@@ -137,4 +137,9 @@ Symbolic* symbolic_analyze(int32_t n, int32_t K, const int64_t* const* indptr, c
 // skip_desc (optional, [nsuper]): descendants whose contributions to dense-tail targets are computed elsewhere (k_outside).
 void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense = false, const uint8_t* skip_desc = nullptr);
 
+// Binary image of an analysis (everything but the lazily built tile combos); `key` = the caller's hash of the inputs the
+// analysis depends on (patterns, permutation, options): symbolic_load returns NULL unless it matches.
+bool symbolic_save(const Symbolic& S, const char* path, uint64_t key);
+Symbolic* symbolic_load(const char* path, uint64_t key);
+
 }  // namespace scilmm

@@ -61,7 +61,7 @@ class HipChainEngine(object):
 
     device_resident = True
 
-    def __init__(self, mats, rank, world, dist, device, perm=None, ordering="amd"):
+    def __init__(self, mats, rank, world, dist, device, perm=None, ordering="amd", cache=None):
         import torch
         from .factor import Symbolic
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
@@ -89,7 +89,9 @@ class HipChainEngine(object):
                 return -1
 
         self._cb = _lib.COMM_FN(_comm)  # keep the callback object alive as long as the engine
-        self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False)
+        # (cache: a directory -- /dev/shm on one node -- where the first rank to analyse the pattern leaves the image of the
+        #  analysis for the others: scilmm_symbolic_save / _load)
+        self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False, cache=cache)
         L = _lib.lib()
         _lib.check(L.scilmm_dist_init(self.sym._h, rank, world, C.c_void_p(self._comm_stream.cuda_stream), self._cb, None), self.sym._h)
         self.sym.upload_values()

@@ -7,6 +7,7 @@ Factor protocol mirrored from what the reference touches on an sksparse Factor
 form of ``factor.L().dot(R)[argsort(P)]`` that never materialises L on the host.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -42,17 +43,45 @@ class Symbolic(object):
             perm = np.ascontiguousarray(perm, dtype=np.int32)
             if perm.shape != (n,):
                 raise ValueError("perm must have length n")
+        cache = opts.pop("cache", None) or os.environ.get("SCILMM_SYMBOLIC_CACHE")
         o = _lib.Options.default(_ORDERINGS[ordering], **opts)
         a = (C.c_void_p * K)(*[x.ctypes.data for x in self._indptr])
         b = (C.c_void_p * K)(*[x.ctypes.data for x in self._indices])
         h = C.c_void_p()
-        st = lib().scilmm_symbolic_create(n, K, a, b, None if perm is None else ptr(perm), C.byref(o), 1, C.byref(h))
+        self.from_cache = False
+        path = key = None
+        if cache:
+            # image of the analysis keyed by everything it depends on: patterns, permutation, ordering, options
+            # (scilmm_symbolic_save / _load: once per pattern and node instead of once per process)
+            key = self._analysis_key(n, perm, ordering, opts)
+            path = os.path.join(cache, "scilmm_symbolic_%016x.bin" % key)
+            if lib().scilmm_symbolic_load(os.fsencode(path), C.c_uint64(key), C.byref(h)) == _lib.OK:
+                self.from_cache = True
+        if not self.from_cache:
+            st = lib().scilmm_symbolic_create(n, K, a, b, None if perm is None else ptr(perm), C.byref(o), 1, C.byref(h))
+            self._h = h
+            check(st, h)
+            if path is not None:
+                os.makedirs(cache, exist_ok=True)
+                lib().scilmm_symbolic_save(h, os.fsencode(path), C.c_uint64(key))  # best effort: a failed write is not an error
         self._h = h
-        check(st, h)
         self._uploaded = False
         self.front_bits = 64
         if upload:
             self.upload_values()
+
+    def _analysis_key(self, n, perm, ordering, opts):
+        import xxhash
+        hx = xxhash.xxh64()
+        hx.update(np.array([n, self.K, _ORDERINGS[ordering]], dtype=np.int64).tobytes())
+        hx.update(repr(sorted(opts.items())).encode())
+        hx.update(repr(sorted((k, v) for k, v in os.environ.items() if k in ("SCILMM_TUNING", "SCILMM_TAIL_WIDE"))).encode())
+        if perm is not None:
+            hx.update(perm.tobytes())
+        for ip, ix in zip(self._indptr, self._indices):
+            hx.update(ip.tobytes())
+            hx.update(ix.tobytes())
+        return hx.intdigest()
 
     def upload_values(self, skip=()):
         for k in range(self.K):

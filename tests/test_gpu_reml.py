@@ -251,3 +251,29 @@ def test_device_resident_evaluation_equals_host_buffer_path(monkeypatch):
         out.append(vals)
     for (n0, g0), (n1, g1) in zip(*out):
         assert abs(n0 - n1) < 1e-12 * abs(n1) and rel_err(g0, g1) < 1e-10
+
+
+def test_metrics_line_and_symbolic_cache(tmp_path):
+    """one JSON record per likelihood evaluation (what was evaluated, what came out, the device timers) and
+    the image of the analysis on disk: a second `SparseCholesky` on the same pattern loads it instead of re-analysing."""
+    import importlib
+    import json
+    P = importlib.import_module("scilmm_amd.SparseCholesky")
+    from scilmm_amd.harness.pedigree import make_problem
+    mats, C, y = make_problem(4000, 0.01, seed=2)
+    A = mats[0]
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    mfile = str(tmp_path / "metrics.jsonl")
+    chol = P.SparseCholesky(cache_dir=str(tmp_path / "sym"), metrics=mfile)
+    np.random.seed(3)
+    out = [P.bolt_gradient_estimation(np.log([0.4, 0.6]), chol, [A, I], C, y, True, 20, False) for _ in range(2)]
+    recs = [json.loads(line) for line in open(mfile)]
+    assert [r["evaluation"] for r in recs] == [1, 2] and recs[0]["n"] == n and recs[0]["K"] == 2
+    assert abs(recs[1]["nll"] - out[1][0]) < 1e-12 * abs(out[1][0]) and len(recs[1]["grad_sigma2"]) == 2
+    assert recs[1]["device_ms"]["factor_ms"] > 0 and recs[1]["device_ms"]["solve_fwd_ms"] > 0 and not recs[0]["symbolic_from_cache"]
+    chol2 = P.SparseCholesky(cache_dir=str(tmp_path / "sym"), metrics=mfile)
+    np.random.seed(3)
+    again = P.bolt_gradient_estimation(np.log([0.4, 0.6]), chol2, [A, I], C, y, True, 20, False)
+    assert chol2.engine_for([A, I]).from_cache
+    assert again[0] == out[0][0] and np.array_equal(again[1], out[0][1])       # same analysis, same bits

@@ -305,3 +305,31 @@ def test_random_patterns_moved_tails_factor_correctly_on_the_cpu_oracle():
         assert np.abs(V @ x - b).max() < 1e-9 * np.abs(b).max()
         assert Symbolic(mats, upload=False, perm=perm, max_width=mw, dense_relax=-1.0).info().nnzL == info.nnzL
     assert tails >= 20 and moved >= 15
+
+
+def test_symbolic_image_round_trip(tmp_path):
+    """scilmm_symbolic_save / _load: the image of an analysis gives back every array bit for bit, is refused under another
+    key (another ordering = another analysis) and when damaged, and a cached handle builds its tile combos on demand."""
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(6000, 0.01, 3)
+    n = A.shape[0]
+    mats = [A, sp.identity(n, format="csr")]
+    d = str(tmp_path)
+    s1 = Symbolic(mats, upload=False, cache=d)
+    s2 = Symbolic(mats, upload=False, cache=d)
+    assert not s1.from_cache and s2.from_cache
+    for name in ["perm", "iperm", "parent", "colcount", "sn_start", "sn_parent", "sn_rowptr", "sn_rows", "sn_loff", "sn_level",
+                 "level_ptr", "level_fronts", "asm_dst", "diag_dst", "upd_ptr", "upd_src", "upd_p0", "upd_p1", "upd_jp0", "tile_base",
+                 "tile_front", "level_tile_ptr", "level_tiles", "level_pair_ptr", "level_pairs", "pat_colptr", "pat_row", "inv_off",
+                 "tail_blk_ptr", "tail_blk", "child_ptr", "child_idx", "val_slot:0", "val_src:0", "val_slot:1", "dense_first"]:
+        assert np.array_equal(s1.get(name), s2.get(name)), name
+    i1, i2 = s1.info(), s2.info()
+    assert all(getattr(i1, f) == getattr(i2, f) for f, _ in i1._fields_)
+    assert np.array_equal(s1.get("combo_ta"), s2.get("combo_ta")) and s2.get("combo_ta").size > 0
+    assert not Symbolic(mats, upload=False, cache=d, ordering="natural").from_cache      # other inputs: other key
+    import os
+    f = [os.path.join(d, x) for x in os.listdir(d) if x.endswith("%016x.bin" % s1._analysis_key(n, None, "amd", {}))][0]
+    with open(f, "r+b") as fh:
+        fh.truncate(os.path.getsize(f) // 2)
+    s3 = Symbolic(mats, upload=False, cache=d)                                            # damaged image: analysed afresh
+    assert not s3.from_cache and np.array_equal(s3.get("perm"), s1.get("perm"))
