@@ -408,12 +408,13 @@ def main():
         # (a --pmc pass of the 1M workload does not finish inside the pool's per-call limit -- counter collection
         # serialises the 8000 launches of a factorization; the 300k pass is on file: profiles/r2_traffic_300k.json)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2_traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%d_traffic_%s.json" % (rr, args.workload)) for rr in (3, 2))
+                      if os.path.exists(q)), "")
+        if tpath:
             # HBM bytes of the update kernel from a separate rocprofv3 --pmc pass of this workload (a PMC pass cannot
             # run inside the timed bench); per launch like `achieved`; the file names its command and corrections
             traffic = json.load(open(tpath))["bytes_per_launch"]
-            traffic_src = "profiles/r2_traffic_%s.json (offline PMC pass, not measured by this run)" % args.workload
+            traffic_src = "%s (offline rocprofv3 --pmc passes of this workload, not measured by this run)" % os.path.relpath(tpath, ROOT)
         upd_s = prof["update_ms"] / 1e3
         n_upd = max(prof["n_update_launches"], 1)
         ach_all = info.update_flops * K / max(upd_s, 1e-12) / 1e12

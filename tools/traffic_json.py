@@ -1,5 +1,5 @@
 """HBM traffic of the update kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
-MI355X_MICROARCH.md prescribes) -> profiles/r2_traffic_<workload>.json, the file bench.py quotes as `roofline.traffic`.
+MI355X_MICROARCH.md prescribes) -> profiles/r<round>_traffic_<workload>.json, the file bench.py quotes as `roofline.traffic`.
 
 usage: traffic_json.py <workload> <fetch_counter_collection.csv> <write_counter_collection.csv> <n_factorizations> <out.json>
 
@@ -24,7 +24,7 @@ def by_kernel(path):
 def main():
     workload, fpath, wpath, nfact, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     f, w = by_kernel(fpath), by_kernel(wpath)
-    upd = [k for k in f.index if k in ("k_dense", "k_dense_g", "k_dense_a", "k_update2", "k_update3", "k_update")]
+    upd = [k for k in f.index if k in ("k_dense", "k_dense_g", "k_dense_a", "k_dense_b", "k_dense32", "k_update2", "k_update3", "k_update")]
     fetch_kb = float(f.loc[upd, "value"].sum()) / nfact
     write_kb = float(w.loc[[k for k in upd if k in w.index], "value"].sum()) / nfact
     launches = float(f.loc[upd, "dispatches"].sum()) / nfact
