@@ -343,6 +343,24 @@ def main():
         fac.solve_dev(ctypes.c_void_p(dB.data_ptr()), r, ctypes.c_void_p(dX.data_ptr()))
         sym.sync()  # (N > 1: every rank ends with all 103 solution columns, as the REML evaluation needs)
 
+    if os.environ.get("SCILMM_PMC_GUARD") == "1" and rank == 0:
+        # Diagnostic for the rocprofv3 --pmc abort at the 1M workload: the tool's frames fault in a
+        # libc copy at the first page BEHIND a mapping that follows libscilmm_hip.so.  Print the neighbourhood and map
+        # readable zero pages into every hole right behind the library's mappings (never over an existing mapping), so
+        # that such an over-read lands on zeros instead of on nothing.
+        libc = ctypes.CDLL(None, use_errno=True)
+        libc.mmap.restype = ctypes.c_void_p
+        libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+        maps = [ln.split() for ln in open("/proc/self/maps")]
+        spans = [(int(m[0].split("-")[0], 16), int(m[0].split("-")[1], 16), m[-1] if len(m) > 5 else "") for m in maps]
+        for i, (a, b, name) in enumerate(spans):
+            if "libscilmm_hip" in name or (i > 0 and "libscilmm_hip" in spans[i - 1][2] and not name):
+                nxt = spans[i + 1][0] if i + 1 < len(spans) else b
+                sys.stderr.write("[maps] %x-%x %s (hole behind it: %d KiB)\n" % (a, b, name, (nxt - b) // 1024))
+                hole = min(nxt - b, 64 << 20)
+                if hole > 0:
+                    got = libc.mmap(ctypes.c_void_p(b), hole, 1, 0x2 | 0x20 | 0x100000, -1, 0)  # PROT_READ, PRIVATE|ANON|FIXED_NOREPLACE
+                    sys.stderr.write("[maps]   guard pages at %x: %s\n" % (b, "ok" if got == b else "not placed"))
     t0 = time.time()
     step(0)  # the plan-building evaluation always runs before the timed region: it is the first warm-up step
     t_first = time.time() - t0

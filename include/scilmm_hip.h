@@ -171,6 +171,16 @@ int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r
 /* Y = A_k X, row-major n x r (SparseCholesky.py:66,70,160,163) */
 int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y);
 
+/* SURVEY section 8f rank 4 -- the exact tr(V^-1 A_k) of the gradient instead of the reference's Monte-Carlo estimate
+ * (scilmm/SparseCholesky.py:49-52, :65).  scilmm_selected_inverse replaces, IN PLACE, every stored entry of the factor by
+ * the entry of Z = (V[P][:,P])^-1 at the same position (Takahashi recursion over the supernodes from the last level
+ * down: Z_RC = -Z_RR (L21 L11^-1), Z_CC = L11^-T L11^-1 - (L21 L11^-1)^T Z_RC; twice the factorization's flops, no
+ * second copy of the factor).  The handle is consumed: refactorize before the next solve.  scilmm_inverse_traces then
+ * returns out[k] = tr(V^-1 A_k) = sum over A_k's pattern of Z_ij A_k,ij for every matrix k (one streaming pass each);
+ * scilmm_export_L on an inverted handle returns the entries of Z on L's pattern.  No counterpart in the reference. */
+int scilmm_selected_inverse(scilmm_factor* fac);
+int scilmm_inverse_traces(scilmm_factor* fac, double* out);
+
 /* BASELINE configs[4] ("fp64 factor with fp32 MFMA fronts"): bits = 32 runs the products of the dense-tail update on
  * the fp32 matrix pipe (operands rounded to fp32 in LDS, every 16-deep chunk summed in fp32, chunks summed in fp64);
  * everything else -- the subtraction from the panel, potrf, trsm, the solves -- stays fp64.  The factor then has a

@@ -63,9 +63,9 @@ class SparseCholesky(object):
         self._ordering_method = ordering_method
         self._perm = perm
         self.fused = fused
-        # opt-in: tr(V^-1 A_k) of the gradient computed exactly instead of by the reference's
-        # Monte-Carlo estimate (SparseCholesky.py:49-52, :65) -- see _exact_traces.  Default off: the default
-        # behaviour has to be the reference's stochastic estimator.
+        # opt-in: tr(V^-1 A_k) of the gradient computed exactly -- selected inverse on the supernodal
+        # factor, on the device -- instead of by the reference's Monte-Carlo estimate (SparseCholesky.py:49-52, :65): see
+        # _exact_traces.  Default off: the default behaviour has to be the reference's stochastic estimator.
         self.exact_trace = exact_trace
         # cache_dir: keep the image of the symbolic analysis there (once per pattern instead of once per process; the
         # reference writes its stage artefacts to files as well, scilmm/IBDCompute.py:82-84); also SCILMM_SYMBOLIC_CACHE.
@@ -263,20 +263,23 @@ def _finish_on_device(torch, sym, fac, R, sig2g_array, covariates, y, reml, sim_
     return nll, grad, fac
 
 
-EXACT_TRACE_MAX_N = 200000
 EXACT_TRACE_BLOCK = 512
 
 
 def _exact_traces(fac, mats):
-    """tr(V^-1 A_k) for every k, exactly: V^-1 E_b for blocks E_b of identity columns (one multi-right-hand-side sweep
-    of the device factor per block), contracted with the matching columns of A_k.  n / EXACT_TRACE_BLOCK sweeps and
-    n^2 doubles over PCIe per evaluation: the brute-force form, meant for n up to ~1e5 (8 s per evaluation at the 100k
-    config); the scalable form -- a selected inverse on the supernodal factor (Takahashi) -- is not built.  Removes
-    the random vectors, and with them np.random, from the objective."""
+    """tr(V^-1 A_k) for every k, exactly: the SELECTED INVERSE on the supernodal factor -- Takahashi
+    recursion on the device, in place (``scilmm_selected_inverse``: twice the factorization's flops, nothing crosses
+    PCIe, no size limit) -- and one streaming pass over each A_k's pattern (``scilmm_inverse_traces``).  Removes the
+    random vectors, and with them np.random, from the objective.  CONSUMES the factor: every caller is done with its
+    solves by then and refactorizes at the next evaluation."""
+    return fac.inverse_traces()
+
+
+def _exact_traces_bruteforce(fac, mats):
+    """The round-2 form, kept as an independent check of the selected inverse (tests): V^-1 E_b for blocks E_b of identity
+    columns (one multi-right-hand-side sweep of the device factor per block), contracted with the matching columns of
+    A_k -- n / EXACT_TRACE_BLOCK sweeps and n^2 doubles over PCIe."""
     n = fac.n
-    if n > EXACT_TRACE_MAX_N:
-        raise ValueError("exact_trace is the brute-force form (n / %d factor sweeps per evaluation): n = %d is beyond its "
-                         "limit of %d" % (EXACT_TRACE_BLOCK, n, EXACT_TRACE_MAX_N))
     cscs = [sparse.csc_matrix(m) for m in mats]
     tr = np.zeros(len(mats))
     for b0 in range(0, n, EXACT_TRACE_BLOCK):

@@ -67,6 +67,7 @@ SYMBOLS = [
     "scilmm_values_download",
     "scilmm_order", "scilmm_fill_count",
     "scilmm_dist_init", "scilmm_dist_work_size", "scilmm_dist_set_work", "scilmm_dist_layout", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments", "scilmm_set_front_precision",
+    "scilmm_selected_inverse", "scilmm_inverse_traces",
     "scilmm_mm_read", "scilmm_mm_export", "scilmm_mm_error", "scilmm_mm_free",
     "scilmm_dominance", "scilmm_dominance_dev", "scilmm_dominance_error",
 ]
@@ -136,6 +137,8 @@ def lib():
     L.scilmm_mm_free.argtypes = [vp]
     L.scilmm_mm_free.restype = None
     L.scilmm_set_front_precision.argtypes = [vp, i32]
+    L.scilmm_selected_inverse.argtypes = [vp]
+    L.scilmm_inverse_traces.argtypes = [vp, vp]
     L.scilmm_he_moments.argtypes = [vp, i32, i32, P(dbl), P(dbl)]
     L.scilmm_dist_init.argtypes = [vp, i32, i32, vp, vp, vp]
     L.scilmm_factor_sizes.argtypes = [vp, P(i64), P(i64), P(i64)]

@@ -111,6 +111,10 @@ struct Dev {
   hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
   std::vector<hipEvent_t> done_ev;      // per level with a distributed front: this rank's kernels of the level finished
   double* ACC = nullptr;                // forward sweep: contributions of this rank's own tail panels, n x RPMAX (dist)
+  // selected inverse (scilmm_selected_inverse): column -> front, per-front offset of Y inside the per-level scratch
+  int32_t* d_col_front = nullptr;
+  int64_t* d_yoff = nullptr;
+  double* d_ybuf = nullptr;
   bool work_external = false;           // W / X / ACC belong to the caller (scilmm_dist_set_work)
   // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
   // prelude -> tail contributions in descendant coordinates (k_outside; fp64 atomics): one launch between the last
@@ -1661,6 +1665,7 @@ struct scilmm_factor {
   int device = -1;            // device of the owning handle (kept here: the factor may outlive its symbolic handle's Dev)
   bool external = false;      // L / invD / logd belong to the caller (scilmm_factor_create_external)
   bool pending = false;       // a factorization has been queued (scilmm_refactorize_async) and not yet waited for
+  bool inverted = false;      // L has been replaced by the selected inverse (scilmm_selected_inverse): no solves until refactorized
   int32_t* h_status = nullptr;  // pinned host copy of *status, filled by the queued copy
 };
 
@@ -1682,6 +1687,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       return SCILMM_ERR_STATE;
     }
   fac->valid = false;
+  fac->inverted = false;
   if (D->world > 1 && (!sym->comm_fn || !D->comm)) {
     sym->err = "multi-GPU: scilmm_dist_init was called without a communication callback / stream";
     return SCILMM_ERR_STATE;
@@ -2805,7 +2811,7 @@ int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double
     int stp = finish_factorize(fac, nullptr);
     if (stp != SCILMM_OK) return stp;
   }
-  if (!fac->valid) return SCILMM_ERR_STATE;
+  if (!fac->valid && !fac->inverted) return SCILMM_ERR_STATE;  // (after scilmm_selected_inverse: the entries of Z on L's pattern)
   Dev* D = (Dev*)sym->device;
   if (D->world > 1) {
     sym->err = "Factor.L(): a distributed factor is not gathered (every rank holds its own tail panels only)";
@@ -2931,6 +2937,131 @@ int scilmm_values_download(scilmm_symbolic* sym, int32_t k, double* slots_out) {
   if (k < 0 || k >= S.K || !D->have_vals[k]) return SCILMM_ERR_STATE;
   const size_t cnt = S.is_diag[k] ? (size_t)S.n : (size_t)S.nnz_pattern;
   HIPCHK(hipMemcpy(slots_out, D->vals[k], cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return SCILMM_OK;
+}
+
+int scilmm_selected_inverse(scilmm_factor* fac) {
+  if (!fac || !fac->sym) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
+  scilmm_symbolic* sym = fac->sym;
+  if (fac->pending) {
+    int stp = finish_factorize(fac, nullptr);
+    if (stp != SCILMM_OK) return stp;
+  }
+  if (!fac->valid) {
+    sym->err = "scilmm_selected_inverse needs a valid factor";
+    return SCILMM_ERR_STATE;
+  }
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  if (D->world > 1) {
+    sym->err = "scilmm_selected_inverse: not available on a distributed factor";
+    return SCILMM_ERR_STATE;
+  }
+  hipStream_t st = D->stream;
+  if (!D->d_col_front) {
+    // column -> front, and where every front's Y = L21 L11^-1 lives inside the per-level scratch
+    std::vector<int32_t> cf((size_t)std::max(S.n, 1), 0);
+    for (int32_t f = 0; f < S.nsuper; ++f)
+      for (int32_t c = S.sn_start[f]; c < S.sn_start[f + 1]; ++c) cf[(size_t)c] = f;
+    std::vector<int64_t> yo((size_t)std::max(S.nsuper, 1), 0);
+    int64_t ymax = 1;
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+      int64_t at = 0;
+      for (int32_t q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+        const int32_t f = S.level_fronts[q];
+        const int64_t w = S.sn_start[f + 1] - S.sn_start[f], u = (S.sn_rowptr[f + 1] - S.sn_rowptr[f]) - w;
+        yo[(size_t)f] = at;
+        at += (u * w + 1) & ~(int64_t)1;
+      }
+      ymax = std::max(ymax, at);
+    }
+    const int32_t* t32;
+    const int64_t* t64;
+    int stq;
+    if ((stq = upload(sym, D, cf, &t32)) != SCILMM_OK) return stq;
+    D->d_col_front = (int32_t*)t32;
+    if ((stq = upload(sym, D, yo, &t64)) != SCILMM_OK) return stq;
+    D->d_yoff = (int64_t*)t64;
+    void* yb = nullptr;
+    HIPCHK(hipMalloc(&yb, sizeof(double) * (size_t)ymax));
+    D->allocs.push_back(yb);
+    D->d_ybuf = (double*)yb;
+  }
+  HIPCHK(hipEventRecord(D->ev[6], st));
+  for (int32_t l = S.nlevels - 1; l >= 0; --l) {
+    const int64_t t0 = D->lv_tile_ptr[l], t1 = D->lv_tile_ptr[l + 1];
+    const int32_t f0 = D->lv_ptr[l], f1 = D->lv_ptr[l + 1];
+    if (f1 == f0) continue;
+    const unsigned nt = (unsigned)(t1 - t0);
+    if (nt > 0) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_sinv_y<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, (const double*)fac->L,
+                           (const double*)fac->invD, D->d_ybuf, (const int64_t*)D->d_yoff);
+      else
+        hipLaunchKernelGGL(k_sinv_y<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, (const double*)fac->L,
+                           (const double*)fac->invD, D->d_ybuf, (const int64_t*)D->d_yoff);
+    }
+    hipLaunchKernelGGL(k_sinv_cc0, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
+                       (const double*)fac->invD);
+    if (nt > 0) {
+      if (D->use_mfma) {
+        hipLaunchKernelGGL(k_sinv_w<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, S.dense_first);
+        hipLaunchKernelGGL(k_sinv_cc<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff);
+      } else {
+        hipLaunchKernelGGL(k_sinv_w<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, S.dense_first);
+        hipLaunchKernelGGL(k_sinv_cc<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff);
+      }
+    }
+  }
+  HIPCHK(hipEventRecord(D->ev[7], st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, D->ev[6], D->ev[7]));
+  D->timing.quad_ms = ms;  // (reported through the quad_ms slot: the selected inverse replaces the trace estimator's sweeps)
+  fac->valid = false;
+  fac->inverted = true;
+  return SCILMM_OK;
+}
+
+int scilmm_inverse_traces(scilmm_factor* fac, double* out) {
+  if (!fac || !fac->sym || !out) return SCILMM_ERR_ARG;
+  DevGuard guard(fac->sym);
+  scilmm_symbolic* sym = fac->sym;
+  if (!fac->inverted) {
+    sym->err = "scilmm_inverse_traces: call scilmm_selected_inverse first";
+    return SCILMM_ERR_STATE;
+  }
+  Dev* D = (Dev*)sym->device;
+  const Symbolic& S = *sym->S;
+  constexpr int NBLK = 1024;
+  int st = ensure_io(sym, D, 2 * NBLK);
+  if (st != SCILMM_OK) return st;
+  hipStream_t s0 = D->stream;
+  double* part = D->IO;
+  std::vector<double> h(2 * NBLK);
+  for (int32_t k = 0; k < S.K; ++k) {
+    if (!D->have_vals[k]) return SCILMM_ERR_STATE;
+    HIPCHK(hipMemsetAsync(part, 0, sizeof(double) * 2 * NBLK, s0));
+    const bool dg = S.is_diag[k];
+    if (!dg && S.nnz_pattern > 0)
+      hipLaunchKernelGGL(k_sinv_trace, dim3(NBLK), dim3(256), 0, s0, S.nnz_pattern, D->v.asm_dst, (const double*)D->vals[k],
+                         (const double*)fac->L, part);
+    if (S.n > 0)
+      hipLaunchKernelGGL(k_sinv_trace_diag, dim3(NBLK), dim3(256), 0, s0, S.n, D->v.pat_colptr, D->v.diag_dst, (const double*)D->vals[k],
+                         dg ? 1 : 0, (const double*)fac->L, part + NBLK);
+    HIPCHK(hipMemcpyAsync(h.data(), part, sizeof(double) * 2 * NBLK, hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipStreamSynchronize(s0));
+    long double all = 0.0L, d1 = 0.0L;
+    for (int b = 0; b < NBLK; ++b) { all += h[b]; d1 += h[NBLK + b]; }
+    out[k] = dg ? (double)d1 : (double)(2.0L * all - d1);  // every off-diagonal pair counts twice (V^-1 and A_k are symmetric)
+  }
+  HIPCHK(hipGetLastError());
   return SCILMM_OK;
 }
 

@@ -2157,6 +2157,295 @@ __global__ __launch_bounds__(256) void k_dot_diag(int32_t n, const int64_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Selected inverse on the supernodal factor (Takahashi / Erisman-Tinney recursion): every stored entry
+// of L is replaced, IN PLACE, by the entry of Z = (V[P][:,P])^-1 at the same position.  For front s with columns C
+// (w of them), rows below R (u = m - w) and stored panel [L11; L21], processed from the LAST level down:
+//     Y    = L21 L11^-1                       (k_sinv_y: the trsm product with the inverse NOT transposed; kept in Ybuf)
+//     Z_RC = - Z_RR Y                         (k_sinv_w: gather-GEMM; R x R entries of Z live in the ancestors' panels)
+//     Z_CC = L11^-T L11^-1 - Y^T Z_RC         (k_sinv_cc0 writes the first term, k_sinv_cc adds the second per row tile)
+// R is a clique of the filled graph, so every Z(r1, r2), r1, r2 in R, is a stored entry of an ancestor: the entry
+// (hi, lo) sits in the panel of the front that owns column lo, at the row of hi -- found by arithmetic in the dense tail
+// (rows = all later columns) and by bisection in a prelude front's row list.  Twice the factorization's flops; the
+// factor is consumed (it has to be refactorized before the next solve).  tr(V^-1 A_k) is then one pass over A_k's
+// pattern slots: sum_e c_e vals_k[e] Z[asm_dst[e]] (k_sinv_trace), c_e = 2 off the diagonal.
+struct SinvOwner {  // where the entries Z(., lo) with lo in one front live
+  int64_t loff;       // panel offset
+  const int32_t* rows;  // row list of the front (prelude fronts: searched)
+  int32_t c0, m;      // first column, panel rows
+  int32_t tail;       // rows = c0 .. n-1: position by arithmetic
+};
+__device__ __forceinline__ SinvOwner sinv_owner(const DevSym& S, const int32_t* __restrict__ col_front, int32_t dense_first, int32_t col) {
+  const int32_t a = col_front[col];
+  SinvOwner o;
+  o.loff = S.sn_loff[a];
+  o.rows = S.sn_rows + S.sn_rowptr[a];
+  o.c0 = S.sn_start[a];
+  o.m = (int32_t)(S.sn_rowptr[a + 1] - S.sn_rowptr[a]);
+  o.tail = a >= dense_first;
+  return o;
+}
+// offset of Z(hi, lo) (hi >= lo) in the panel of lo's owner
+__device__ __forceinline__ int64_t sinv_offset(const SinvOwner& o, int32_t hi, int32_t lo) {
+  int32_t pos;
+  if (o.tail) {
+    pos = hi - o.c0;
+  } else {
+    int32_t a = 0, b = o.m;
+    while (a < b) {  // first position whose row label is >= hi (hi is in the list: R is a clique)
+      const int32_t mid = (a + b) >> 1;
+      if (o.rows[mid] < hi) a = mid + 1; else b = mid;
+    }
+    pos = a;
+  }
+  return o.loff + (int64_t)(lo - o.c0) * o.m + pos;
+}
+
+// Y tile = L21 tile * L11^-1 (128 x w x w), written column-major (leading dimension u) into Ybuf[yoff[front]]
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_sinv_y(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
+                                                const double* __restrict__ invD, double* __restrict__ Ybuf,
+                                                const int64_t* __restrict__ yoff) {
+  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  if (R0 + nrow <= w) return;
+  const int32_t u = m - w;
+  const int ncb = (w + 15) >> 4;
+  const double* P = L + S.sn_loff[s];
+  const double* I = invD + S.inv_off[s];
+  double* Y = Ybuf + yoff[s];
+  d4 acc[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int t = tid & 127, ka = tid >> 7;
+  const int q = tid % NB, kb = tid / NB;
+  const bool ha = t < nrow, hb = q < w;
+  for (int32_t k0 = 0; k0 < w; k0 += KCS) {
+    const int kc = min(KCS, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (k0 > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KCS / 2; ++i) {
+      const int k = ka + 2 * i;
+      if (k < kc4) As[k * LDA + t] = (ha && k < kc) ? P[(int64_t)(k0 + k) * m + R0 + t] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < KCS / (256 / NB); ++i) {
+      const int k = kb + (256 / NB) * i;
+      // Bop[k][j] = invL[k][j] (NOT transposed; k_trsm stages invL[j][k]); invL is stored column-major w x w
+      if (k < kc4) Bs[k * LDB + q] = (hb && k < kc) ? I[(int64_t)q * w + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
+  }
+  const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 32 * wv + 16 * ib + li;
+        if (i < nrow && R0 + i >= w && j < w) Y[(int64_t)j * u + (R0 + i - w)] = acc[jb][ib][r];
+      }
+}
+
+// Z_RC tile = - sum_k Z(r_i, r_k) Y[k, :]  over all rows k of R, the Z entries gathered from the ancestors' panels
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_sinv_w(DevSym S, const int32_t* __restrict__ tiles, double* L,
+                                                const double* __restrict__ Ybuf, const int64_t* __restrict__ yoff,
+                                                const int32_t* __restrict__ col_front, int32_t dense_first) {
+  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];  // [k][i] = Z(r_i, r_k)
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];  // [k][j] = Y[k][j]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  if (R0 + nrow <= w) return;
+  const int32_t u = m - w;
+  const int ncb = (w + 15) >> 4;
+  double* P = L + S.sn_loff[s];
+  const double* Y = Ybuf + yoff[s];
+  d4 acc[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  constexpr int PA = KCS / 2, PB = KCS / (256 / NB);
+  const int t = tid & 127, ka = tid >> 7;
+  const int q = tid % NB, kb = tid / NB;
+  const bool ha = t < nrow && R0 + t >= w, hb = q < w;
+  const int32_t gi = ha ? rs[R0 + t] : 0;
+  const SinvOwner oi = sinv_owner(S, col_front, dense_first, gi);  // used where r_i < r_k: the entry lives with r_i's owner
+  double ra[PA], rb[PB];
+  auto fetch = [&](int k0) {
+    const int kc = min(KCS, u - k0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = ka + 2 * i;
+      double v = 0.0;
+      if (ha && k < kc) {
+        const int32_t gk = rs[w + k0 + k];
+        if (gi >= gk) {
+          const SinvOwner ok = sinv_owner(S, col_front, dense_first, gk);
+          v = L[sinv_offset(ok, gi, gk)];
+        } else {
+          v = L[sinv_offset(oi, gk, gi)];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = kb + (256 / NB) * i;
+      rb[i] = (hb && k < kc) ? Y[(int64_t)q * u + k0 + k] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int32_t k0 = 0; k0 < u; k0 += KCS) {
+    const int kc = min(KCS, u - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (k0 > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = ka + 2 * i;
+      if (k < kc4) As[k * LDA + t] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = kb + (256 / NB) * i;
+      if (k < kc4) Bs[k * LDB + q] = rb[i];
+    }
+    if (k0 + KCS < u) fetch(k0 + KCS);
+    __syncthreads();
+    if (32 * wv < nrow) tile_mma<MFMA>(As, Bs, kc4, ncb, lane, wv, acc);
+  }
+  const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jb + lr + 4 * r;
+        const int i = 32 * wv + 16 * ib + li;
+        if (i < nrow && R0 + i >= w && j < w) P[(int64_t)j * m + R0 + i] = -acc[jb][ib][r];
+      }
+}
+
+// diagonal block <- L11^-T L11^-1 (lower triangle; the strict upper part stays zero), one workgroup per front
+__global__ __launch_bounds__(256) void k_sinv_cc0(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
+                                                  const double* __restrict__ invD) {
+  const int32_t s = fronts[blockIdx.x];
+  const int32_t w = S.sn_start[s + 1] - S.sn_start[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  double* P = L + S.sn_loff[s];
+  const double* I = invD + S.inv_off[s];  // X = L11^-1, column-major, lower triangular
+  for (int idx = threadIdx.x; idx < w * w; idx += 256) {
+    const int b = idx / w, a = idx - b * w;  // entry (row a, column b), a >= b
+    if (a < b) continue;
+    double sum = 0.0;
+    for (int k = a; k < w; ++k) sum += I[(int64_t)a * w + k] * I[(int64_t)b * w + k];  // sum_k X[k][a] X[k][b], X[k][a] = 0 for k < a
+    P[(int64_t)b * m + a] = sum;
+  }
+}
+
+// diagonal block -= Y_I^T Z_RC,I for one 128-row tile I of R (fp64 atomics: the tiles of a front add up in any order)
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_sinv_cc(DevSym S, const int32_t* __restrict__ tiles, double* L,
+                                                 const double* __restrict__ Ybuf, const int64_t* __restrict__ yoff) {
+  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];  // [k = row of the tile][a] = Y[row][a]
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];  // [k][b] = Z_RC[row][b]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int32_t g = tiles[blockIdx.x];
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t w = S.sn_start[s + 1] - S.sn_start[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM;
+  const int32_t nrow = min(TM, m - R0);
+  if (R0 + nrow <= w) return;
+  const int32_t u = m - w;
+  const int ncb = (w + 15) >> 4;
+  double* P = L + S.sn_loff[s];
+  const double* Y = Ybuf + yoff[s];
+  d4 acc[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int cq = tid & 127, kh = tid >> 7;  // column a (or b) and row parity inside a 16-row chunk
+  for (int32_t i0 = 0; i0 < nrow; i0 += KCS) {
+    if (i0 > 0) __syncthreads();
+#pragma unroll
+    for (int x = 0; x < KCS / 2; ++x) {
+      const int k = kh + 2 * x;
+      const int32_t row = R0 + i0 + k;  // panel row
+      const bool on = i0 + k < nrow && row >= w && cq < w;
+      As[k * LDA + cq] = on ? Y[(int64_t)cq * u + (row - w)] : 0.0;
+      Bs[k * LDB + cq] = on ? P[(int64_t)cq * m + row] : 0.0;
+    }
+    __syncthreads();
+    if (32 * wv < w) tile_mma<MFMA>(As, Bs, KCS, ncb, lane, wv, acc);  // D[b][a] += sum_k Z_RC[k][b] Y[k][a]
+  }
+  const int li = lane & 15, lr = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = 16 * jb + lr + 4 * r;      // column of the diagonal block
+        const int a = 32 * wv + 16 * ib + li;    // row
+        if (a < w && b <= a) unsafeAtomicAdd(&P[(int64_t)b * m + a], -acc[jb][ib][r]);
+      }
+}
+
+// part[block] = sum over this block's slots of vals[e] * Z[asm_dst[e]] (all slots once); the caller doubles it and takes
+// the diagonal slots (k_sinv_trace_diag) off once
+__global__ __launch_bounds__(256) void k_sinv_trace(int64_t nnz, const int64_t* __restrict__ asm_dst, const double* __restrict__ vals,
+                                                    const double* __restrict__ Z, double* __restrict__ part) {
+  double acc = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) acc += vals[e] * Z[asm_dst[e]];
+  __shared__ double red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// diag_vals: per permuted column j the value of the matrix on the diagonal: vals[pat_colptr[j]] (general matrix; the
+// diagonal slot comes first in its column) or vals[j] (diagonal-only matrix)
+__global__ __launch_bounds__(256) void k_sinv_trace_diag(int32_t n, const int64_t* __restrict__ pat_colptr, const int64_t* __restrict__ diag_dst,
+                                                         const double* __restrict__ vals, int32_t is_diag, const double* __restrict__ Z,
+                                                         double* __restrict__ part) {
+  double acc = 0.0;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256)
+    acc += (is_diag ? vals[j] : vals[pat_colptr[j]]) * Z[diag_dst[j]];
+  __shared__ double red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // IBD (numerator relationship) values ON THE DEVICE, straight into the value slots of the engine (SURVEY 8f rank 1;
 // reference scilmm/Matrices/Numerator.py:5-38 computes A = L D L^T in interpreted Python).  Tabular recursion on the
 // known pattern (pairs with a common ancestor): for individuals i > j in pedigree order (parents before children, so i

@@ -258,6 +258,15 @@ class Factor(object):
     def lmul_dev(self, dR_ptr, r, dZ_ptr):
         check(lib().scilmm_lmul_dev(self._h, dR_ptr, r, dZ_ptr), self.sym._h)
 
+    def inverse_traces(self):
+        """tr(V^-1 A_k) for every matrix of the analysis, exactly: the selected inverse on the supernodal factor (Takahashi
+        recursion on the device, in place) followed by one pass over each A_k's pattern.  CONSUMES the factor: it must be
+        refactorized before the next solve."""
+        check(lib().scilmm_selected_inverse(self._h), self.sym._h)
+        out = np.empty(self.sym.K)
+        check(lib().scilmm_inverse_traces(self._h, ptr(out)), self.sym._h)
+        return out
+
     def logdet(self):
         out = C.c_double(0.0)
         check(lib().scilmm_logdet(self._h, C.byref(out)), self.sym._h)

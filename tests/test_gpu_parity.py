@@ -579,3 +579,30 @@ def test_ibd_values_built_on_the_device_match_reference_goldens_bit_for_bit():
             assert f.logdet() == ref.logdet()
     with pytest.raises(Exception):
         sym.ibd_values_from_pedigree(0, par[::-1].copy())   # not in pedigree order
+
+
+def test_integration_stub_from_the_document_runs():
+    """INTEGRATION.md section 2 shows the ~25-line ctypes stub a reference maintainer would put in place of
+    scilmm/SparseCholesky.py:16-26.  The code block is taken from the document verbatim (only the library path is made
+    absolute) and executed: the object it returns obeys the four-member factor protocol and agrees with the oracle."""
+    import os
+    import re
+    import torch  # noqa: F401  (the HIP runtime torch ships must be the one in the process: see scilmm_amd/_lib.py)
+    from oracle import oracle as O
+    from scilmm_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 2."):doc.index("## 3.")]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert 'C.CDLL("libscilmm_hip.so")' in code
+    ns = {}
+    exec(code.replace('C.CDLL("libscilmm_hip.so")', "C.CDLL(%r)" % _lib.LIB_PATH), ns)
+    A = random_spd(200, 0.05, 21)
+    f = ns["SparseCholesky"]()(A)
+    o = O.OracleFactor(A, f.P())
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((200, 3))
+    assert abs(f.logdet() - o.logdet()) < TOL * abs(o.logdet())
+    assert rel_err(f(B), o(B)) < TOL and f(B[:, 0]).shape == (200,)
+    assert rel_err(f.L().toarray(), o.L().toarray()) < TOL
+    assert sorted(f.P().tolist()) == list(range(200))

@@ -193,10 +193,13 @@ def test_he_moments_on_device_match_host():
 
 
 def test_exact_trace_option_gives_the_analytic_gradient():
-    """exact_trace=True (opt-in): tr(V^-1 A_k) by blocked identity solves instead of the Monte-Carlo
-    estimate -- equal to the dense inverse's trace, gradient = central finite difference of the (now deterministic)
-    objective, REML result independent of the np.random seed; the default path still draws its random vectors."""
+    """exact_trace=True (opt-in): tr(V^-1 A_k) from the SELECTED INVERSE on the supernodal factor
+    (Takahashi recursion on the device, in place) instead of the Monte-Carlo estimate.  The entries of Z on L's pattern
+    equal the dense inverse's (1e-9), the traces equal the dense inverse's and the brute-force identity-solve form's,
+    gradient = central finite difference of the (now deterministic) objective, REML result independent of the np.random
+    seed; the default path still draws its random vectors; a consumed factor refuses solves until it is refactorized."""
     M = importlib.import_module("scilmm_amd.SparseCholesky")  # (the package attribute of that name is the class)
+    from scilmm_amd._lib import ScilmmError
     from scilmm_amd.harness import pedigree as H
     mats, C, y = H.make_problem(2500, 0.01, seed=4, with_dominance=True)
     mats = mats + [sp.identity(y.size, format="csr")]
@@ -210,9 +213,20 @@ def test_exact_trace_option_gives_the_analytic_gradient():
     V = sum(s * m for s, m in zip(np.exp(x0), mats)).toarray()
     Vi = np.linalg.inv(V)
     fac = chol._factor_state[id(chol.engine_for(mats))]
+    with pytest.raises(ScilmmError):
+        fac(y)                                            # the evaluation consumed the factor (it holds Z now)
+    fac.refactorize(np.exp(x0))
+    brute = M._exact_traces_bruteforce(fac, mats)
     tr = M._exact_traces(fac, mats)
     for k, m in enumerate(mats):
-        assert abs(tr[k] - np.sum(Vi * m.toarray())) < 1e-9 * abs(tr[k])
+        want = np.sum(Vi * m.toarray())
+        assert abs(tr[k] - want) < 1e-9 * abs(want) and abs(brute[k] - want) < 1e-9 * abs(want)
+    # every stored entry: Z on the pattern of L, permuted labels
+    P = fac.P()
+    Zs = fac.L()                                          # (on an inverted handle: the selected inverse's entries)
+    Zd = Vi[np.ix_(P, P)]
+    rows, cols = Zs.nonzero()
+    assert rows.size > n and np.abs(np.asarray(Zs[rows, cols]).ravel() - Zd[rows, cols]).max() < 1e-9 * np.abs(Zd).max()
     h = 1e-5
     for k in range(3):
         e = np.zeros(3)
@@ -226,31 +240,33 @@ def test_exact_trace_option_gives_the_analytic_gradient():
         # (REML appends the identity itself, SparseCholesky.py:178)
         res.append(M.REML(M.SparseCholesky(exact_trace=True), mats[:-1], C, y, verbose=False)["covariance coefficients"])
     assert rel_err(res[0], res[1]) < 1e-8  # (to rounding: the chain sweeps of the solves sum in arrival order)
-    with pytest.raises(ValueError):
-        M.EXACT_TRACE_MAX_N, keep = 10, M.EXACT_TRACE_MAX_N
-        try:
-            M.bolt_gradient_estimation(x0, chol, mats, C, y, True, 100, False)
-        finally:
-            M.EXACT_TRACE_MAX_N = keep
 
 
-def test_device_resident_evaluation_equals_host_buffer_path(monkeypatch):
-    """The evaluation keeps its n x 100 blocks in HBM (torch buffers + the `_dev` entry points) when torch reaches the GPU;
-    SCILMM_HOST_BUFFERS=1 forces the host-buffer path.  Same operations, same np.random stream: same numbers."""
-    Pm = importlib.import_module("scilmm_amd.SparseCholesky")
-    from scilmm_amd.harness import pedigree as H
-    mats, C, y = H.make_problem(6000, 0.01, seed=2)
-    mats = mats + [sp.identity(y.size, format="csr")]
-    assert Pm._device_buffers() is not None
-    out = []
-    for host in ("0", "1"):
-        monkeypatch.setenv("SCILMM_HOST_BUFFERS", host)
-        np.random.seed(7)
-        chol = Pm.SparseCholesky()
-        vals = [Pm.bolt_gradient_estimation(np.log([0.4, 0.6]) + 0.05 * i, chol, mats, C, y, True, 100, False) for i in range(2)]
-        out.append(vals)
-    for (n0, g0), (n1, g1) in zip(*out):
-        assert abs(n0 - n1) < 1e-12 * abs(n1) and rel_err(g0, g1) < 1e-10
+def test_selected_inverse_traces_at_100k_against_identity_solves():
+    """The selected inverse at BASELINE configs[1]'s size (100k individuals, K = 2; 1.7 TFLOP factor, 3.4 TFLOP inversion):
+    tr(V^-1 A) and tr(V^-1) against the brute-force form (163 multi-column sweeps of the factor, 55 GB over PCIe) to 1e-8,
+    tr(V^-1 V) = n, and the time of both."""
+    import time
+    M = importlib.import_module("scilmm_amd.SparseCholesky")
+    from scilmm_amd.harness.pedigree import make_problem
+    mats, C, y = make_problem(100000, 0.005, seed=0)
+    A = mats[0]
+    n = A.shape[0]
+    I = sp.identity(n, format="csr")
+    chol = M.SparseCholesky()
+    sym = chol.engine_for([A, I])
+    s2 = np.array([0.4, 0.6])
+    fac = sym.factorize(s2)
+    t0 = time.time()
+    brute = M._exact_traces_bruteforce(fac, [A, I])
+    t_brute = time.time() - t0
+    t0 = time.time()
+    tr = M._exact_traces(fac, [A, I])
+    t_sel = time.time() - t0
+    print("100k: selected inverse %.2f s, identity solves %.1f s; traces %s" % (t_sel, t_brute, tr))
+    assert np.abs(tr - brute).max() < 1e-8 * np.abs(brute).max()
+    assert abs(s2 @ tr - n) < 1e-9 * n                   # tr(V^-1 V) = n
+    assert t_sel < t_brute
 
 
 def test_metrics_line_and_symbolic_cache(tmp_path):
