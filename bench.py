@@ -433,6 +433,16 @@ def main():
             # run inside the timed bench); per launch like `achieved`; the file names its command and corrections
             traffic = json.load(open(tpath))["bytes_per_launch"]
             traffic_src = "%s (offline rocprofv3 --pmc passes of this workload, not measured by this run)" % os.path.relpath(tpath, ROOT)
+        iso = os.path.join(ROOT, "profiles", "r3_traffic_%s_isolated_kernel.json" % args.workload)
+        traffic_per_flop = None
+        if traffic is None and os.path.exists(iso):
+            # no in-situ PMC pass exists for this workload (rocprofv3 --pmc aborts at 1M: the file says how): HBM bytes per
+            # flop of the dominant kernel from a PMC pass of that kernel ALONE on items of this workload's shape, scaled to
+            # this run's flops per launch below
+            traffic_per_flop = 1.0 / json.load(open(iso))["flop_per_byte"]
+            traffic_src = ("%s: bytes per flop of the dominant kernel alone at this workload's shape (rocprofv3 --pmc FETCH_SIZE / "
+                           "WRITE_SIZE passes of csrc/tools/dense_bench2) x this run's flops per launch; an in-situ --pmc pass "
+                           "of this workload aborts inside the profiler" % os.path.relpath(iso, ROOT))
         upd_s = prof["update_ms"] / 1e3
         n_upd = max(prof["n_update_launches"], 1)
         ach_all = info.update_flops * K / max(upd_s, 1e-12) / 1e12
@@ -468,6 +478,8 @@ def main():
                            "(generation %.0f s, analysis %.0f s, first evaluation incl. device plan %.0f s%s)"
                            % (t_step_est, args.budget_s, t_gen, t_sym, t_first,
                               ", %.0f s reserved for the CPU baseline" % reserve if reserve else ""))
+        if traffic is None and traffic_per_flop is not None:
+            traffic = traffic_per_flop * flops_k / max(n_k, 1)
         out = {
             "metric": ("REML factorize+solve nnz(L)/s (simulated pedigree, fp64)" if not comps else
                        "REML factorize+solve nnz(L)/s (simulated pedigree, K=3 A+D+I, fp64: configs[4]'s model, NOT the headline)") if args.front_bits == 64 else
