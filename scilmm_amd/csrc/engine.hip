@@ -115,6 +115,12 @@ struct Dev {
   int32_t* d_col_front = nullptr;
   int64_t* d_yoff = nullptr;
   double* d_ybuf = nullptr;
+  int32_t* d_sinv_pre_tiles = nullptr;        // tiles of the non-tail fronts, by level (k_sinv_w)
+  std::vector<int64_t> sinv_pre_ptr;          // [nlevels+1]
+  std::vector<int32_t> sinv_tail_front;       // [nlevels] the dense-tail front of the level, or -1
+  int32_t* d_sinv_tail_fronts = nullptr;      // the tail fronts, one per entry (k_sinv_zero takes a list)
+  SinvWork* d_sinv_work = nullptr;            // items of k_sinv_tail, grouped by tail front
+  std::vector<int64_t> sinv_work_ptr;         // [ntail+1]
   bool work_external = false;           // W / X / ACC belong to the caller (scilmm_dist_set_work)
   // dense tail (Symbolic::dense_first): implicit work items of k_dense, early (side streams) and late (main stream)
   // prelude -> tail contributions in descendant coordinates (k_outside; fp64 atomics): one launch between the last
@@ -2960,62 +2966,127 @@ int scilmm_selected_inverse(scilmm_factor* fac) {
   }
   hipStream_t st = D->stream;
   if (!D->d_col_front) {
-    // column -> front, and where every front's Y = L21 L11^-1 lives inside the per-level scratch
+    // column -> front, where every front's Y = L21 L11^-1 lives inside the per-level scratch (dense-tail fronts keep it
+    // transposed, [u][128]), the non-tail tiles by level, and the items of the dense-tail kernel
     std::vector<int32_t> cf((size_t)std::max(S.n, 1), 0);
     for (int32_t f = 0; f < S.nsuper; ++f)
       for (int32_t c = S.sn_start[f]; c < S.sn_start[f + 1]; ++c) cf[(size_t)c] = f;
     std::vector<int64_t> yo((size_t)std::max(S.nsuper, 1), 0);
     int64_t ymax = 1;
+    D->sinv_tail_front.assign((size_t)std::max(S.nlevels, 1), -1);
+    D->sinv_pre_ptr.assign((size_t)S.nlevels + 1, 0);
+    std::vector<int32_t> pre_tiles;
     for (int32_t l = 0; l < S.nlevels; ++l) {
       int64_t at = 0;
       for (int32_t q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
         const int32_t f = S.level_fronts[q];
         const int64_t w = S.sn_start[f + 1] - S.sn_start[f], u = (S.sn_rowptr[f + 1] - S.sn_rowptr[f]) - w;
         yo[(size_t)f] = at;
-        at += (u * w + 1) & ~(int64_t)1;
+        at += ((f >= S.dense_first ? u * NB : u * w) + 1) & ~(int64_t)1;
+        if (f >= S.dense_first) D->sinv_tail_front[(size_t)l] = f;
       }
       ymax = std::max(ymax, at);
+      for (int64_t q = S.level_tile_ptr[l]; q < S.level_tile_ptr[l + 1]; ++q)
+        if (S.tile_front[S.level_tiles[q]] < S.dense_first) pre_tiles.push_back(S.level_tiles[q]);
+      D->sinv_pre_ptr[(size_t)l + 1] = (int64_t)pre_tiles.size();
     }
+    // dense-tail items: (front s, 256 rows of R, a range of later fronts); about 1024 items per front
+    std::vector<SinvWork> sw;
+    std::vector<int32_t> tails;
+    const int32_t nT = S.nsuper - S.dense_first;
+    D->sinv_work_ptr.assign((size_t)nT + 1, 0);
+    for (int32_t jj = 0; jj < nT; ++jj) {
+      const int32_t f = S.dense_first + jj;
+      tails.push_back(f);
+      const int64_t w = S.sn_start[f + 1] - S.sn_start[f], u = (int64_t)S.n - S.sn_start[f] - w;
+      const int32_t count = S.nsuper - 1 - f;  // later fronts
+      if (u > 0 && count > 0) {
+        const int64_t ntile = (u + 255) / 256;
+        const int32_t nseg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(count, 1024 / ntile));
+        for (int32_t sg = 0; sg < nseg; ++sg) {
+          const int32_t ka = f + 1 + (int32_t)((int64_t)count * sg / nseg), kb = f + 1 + (int32_t)((int64_t)count * (sg + 1) / nseg);
+          if (kb <= ka) continue;
+          for (int64_t q = 0; q < ntile; ++q) sw.push_back(SinvWork{f, (int32_t)q, ka, kb});
+        }
+      }
+      D->sinv_work_ptr[(size_t)jj + 1] = (int64_t)sw.size();
+    }
+    if (sw.empty()) sw.push_back(SinvWork{0, 0, 0, 0});
+    if (tails.empty()) tails.push_back(0);
+    if (pre_tiles.empty()) pre_tiles.push_back(0);
     const int32_t* t32;
     const int64_t* t64;
+    const SinvWork* tsw;
     int stq;
     if ((stq = upload(sym, D, cf, &t32)) != SCILMM_OK) return stq;
     D->d_col_front = (int32_t*)t32;
     if ((stq = upload(sym, D, yo, &t64)) != SCILMM_OK) return stq;
     D->d_yoff = (int64_t*)t64;
+    if ((stq = upload(sym, D, pre_tiles, &t32)) != SCILMM_OK) return stq;
+    D->d_sinv_pre_tiles = (int32_t*)t32;
+    if ((stq = upload(sym, D, tails, &t32)) != SCILMM_OK) return stq;
+    D->d_sinv_tail_fronts = (int32_t*)t32;
+    if ((stq = upload(sym, D, sw, &tsw)) != SCILMM_OK) return stq;
+    D->d_sinv_work = (SinvWork*)tsw;
     void* yb = nullptr;
     HIPCHK(hipMalloc(&yb, sizeof(double) * (size_t)ymax));
     D->allocs.push_back(yb);
     D->d_ybuf = (double*)yb;
+    if (!D->d_zeros) {
+      HIPCHK(hipMalloc((void**)&D->d_zeros, 2048));
+      HIPCHK(hipMemset(D->d_zeros, 0, 2048));
+    }
+    HIPCHK(hipFuncSetAttribute((const void*)k_sinv_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   }
   HIPCHK(hipEventRecord(D->ev[6], st));
+  const char* egen = tune_env("SCILMM_SINV_GENERIC");  // 1: the gather kernel for the dense tail as well (the round's first form)
+  const bool tail_kernel = D->use_mfma && !(egen && egen[0] == '1');
   for (int32_t l = S.nlevels - 1; l >= 0; --l) {
     const int64_t t0 = D->lv_tile_ptr[l], t1 = D->lv_tile_ptr[l + 1];
     const int32_t f0 = D->lv_ptr[l], f1 = D->lv_ptr[l + 1];
     if (f1 == f0) continue;
     const unsigned nt = (unsigned)(t1 - t0);
+    const int32_t tf = tail_kernel ? D->sinv_tail_front[(size_t)l] : -1;
+    // tiles that go through the gather kernel: all of the level's, or the non-tail fronts' only
+    const int32_t* wt = tf >= 0 ? D->d_sinv_pre_tiles + D->sinv_pre_ptr[(size_t)l] : D->d_level_tiles + t0;
+    const unsigned nwt = tf >= 0 ? (unsigned)(D->sinv_pre_ptr[(size_t)l + 1] - D->sinv_pre_ptr[(size_t)l]) : nt;
+    const int32_t ydf = tail_kernel ? S.dense_first : S.nsuper;  // fronts from here on keep Y transposed
     if (nt > 0) {
       if (D->use_mfma)
         hipLaunchKernelGGL(k_sinv_y<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, (const double*)fac->L,
-                           (const double*)fac->invD, D->d_ybuf, (const int64_t*)D->d_yoff);
+                           (const double*)fac->invD, D->d_ybuf, (const int64_t*)D->d_yoff, ydf);
       else
         hipLaunchKernelGGL(k_sinv_y<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, (const double*)fac->L,
-                           (const double*)fac->invD, D->d_ybuf, (const int64_t*)D->d_yoff);
+                           (const double*)fac->invD, D->d_ybuf, (const int64_t*)D->d_yoff, ydf);
     }
     hipLaunchKernelGGL(k_sinv_cc0, dim3((unsigned)(f1 - f0)), dim3(256), 0, st, D->v, D->d_level_fronts + f0, fac->L,
                        (const double*)fac->invD);
-    if (nt > 0) {
-      if (D->use_mfma) {
-        hipLaunchKernelGGL(k_sinv_w<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
-                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, S.dense_first);
-        hipLaunchKernelGGL(k_sinv_cc<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
-                           (const int64_t*)D->d_yoff);
-      } else {
-        hipLaunchKernelGGL(k_sinv_w<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
-                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, S.dense_first);
-        hipLaunchKernelGGL(k_sinv_cc<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
-                           (const int64_t*)D->d_yoff);
+    if (tf >= 0) {
+      const int32_t jj = tf - S.dense_first;
+      const int64_t i0 = D->sinv_work_ptr[(size_t)jj], i1 = D->sinv_work_ptr[(size_t)jj + 1];
+      if (i1 > i0) {
+        const int32_t wtf = S.sn_start[tf + 1] - S.sn_start[tf];
+        hipLaunchKernelGGL(k_sinv_zero, dim3(1, (unsigned)wtf), dim3(256), 0, st, D->v, (const int32_t*)(D->d_sinv_tail_fronts + jj), fac->L);
+        hipLaunchKernelGGL(k_sinv_tail, dim3((unsigned)(i1 - i0)), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), st, D->v,
+                           S.dense_first, (const SinvWork*)(D->d_sinv_work + i0), fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, (const double*)D->d_zeros);
       }
+    }
+    if (nwt > 0) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_sinv_w<true>, dim3(nwt), dim3(256), 0, st, D->v, wt, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, S.dense_first);
+      else
+        hipLaunchKernelGGL(k_sinv_w<false>, dim3(nwt), dim3(256), 0, st, D->v, wt, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, (const int32_t*)D->d_col_front, S.dense_first);
+    }
+    if (nt > 0) {
+      if (D->use_mfma)
+        hipLaunchKernelGGL(k_sinv_cc<true>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, ydf);
+      else
+        hipLaunchKernelGGL(k_sinv_cc<false>, dim3(nt), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, (const double*)D->d_ybuf,
+                           (const int64_t*)D->d_yoff, ydf);
     }
   }
   HIPCHK(hipEventRecord(D->ev[7], st));

@@ -2204,7 +2204,7 @@ __device__ __forceinline__ int64_t sinv_offset(const SinvOwner& o, int32_t hi, i
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_sinv_y(DevSym S, const int32_t* __restrict__ tiles, const double* __restrict__ L,
                                                 const double* __restrict__ invD, double* __restrict__ Ybuf,
-                                                const int64_t* __restrict__ yoff) {
+                                                const int64_t* __restrict__ yoff, int32_t dense_first) {
   __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
   __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2256,7 +2256,11 @@ __global__ __launch_bounds__(256) void k_sinv_y(DevSym S, const int32_t* __restr
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jb + lr + 4 * r;
         const int i = 32 * wv + 16 * ib + li;
-        if (i < nrow && R0 + i >= w && j < w) Y[(int64_t)j * u + (R0 + i - w)] = acc[jb][ib][r];
+        if (i < nrow && R0 + i >= w && j < w) {
+          // dense-tail fronts keep Y TRANSPOSED ([u][128]: the k-rows k_sinv_tail's LDS-DMA copies), the others column-major
+          if (s >= dense_first) Y[(int64_t)(R0 + i - w) * NB + j] = acc[jb][ib][r];
+          else Y[(int64_t)j * u + (R0 + i - w)] = acc[jb][ib][r];
+        }
       }
 }
 
@@ -2348,6 +2352,169 @@ __global__ __launch_bounds__(256) void k_sinv_w(DevSym S, const int32_t* __restr
       }
 }
 
+// Z_RC of a DENSE-TAIL front through the dense-tail kernel's machinery (k_dense_b): the R x R part of Z is the trailing
+// dense matrix, so nothing is searched.  Item = (front s, 256 rows of R, a range of later tail fronts K as the reduction
+// dimension):   acc[256 x w] += sum_{k in cols(K)} Z(g_i, g_k) Y[k, :].
+//  * B operand: Y^T rows (k-row = 128 contiguous doubles in the front's scratch: k_sinv_y writes Y TRANSPOSED for tail
+//    fronts), by LDS-DMA, 64 deep, double-buffered -- exactly k_dense_b's B stream;
+//  * A operand: Z(g_i, g_k) straight from the panels into registers.  g_i >= g_k: the entry sits in the panel of K at row
+//    g_i (k_dense_b's access: 16 consecutive rows = 128 contiguous bytes); g_i < g_k: it sits in the panel that owns column
+//    g_i, at row g_k -- "transposed": a lane reads along the reduction dimension (4 consecutive k = 32 contiguous bytes,
+//    the rest of the 128-byte line is used by the next k-steps out of L1).  Chosen per element, so the blocks on the
+//    diagonal need no special case.
+//  * the sum is ADDED to the panel with fp64 atomics (the front's rows were zeroed after Y was taken): several K ranges
+//    of one row tile run as separate workgroups, which is what keeps a launch at >= 1000 items for every front.
+struct SinvWork {
+  int32_t front;   // tail front s
+  int32_t q;       // rows [256 q, 256 q + 256) of R
+  int32_t ka, kb;  // source fronts [ka, kb) (absolute front ids, all > s)
+};
+__global__ __launch_bounds__(512, 1) void k_sinv_tail(DevSym S, int32_t dense_first, const SinvWork* __restrict__ work, double* L,
+                                                      const double* __restrict__ Ybuf, const int64_t* __restrict__ yoff,
+                                                      const int32_t* __restrict__ col_front, const double* __restrict__ zeros) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [2][KBA][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const SinvWork wk = work[blockIdx.x];
+  const int32_t s = wk.front;
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = S.n - c0, u = m - w;
+  const int32_t c1 = c0 + w;                 // first global column of R
+  const int32_t r0 = 256 * wk.q;             // first row of the item inside R
+  const int32_t nrow = min(256, u - r0);
+  const int32_t ia = 32 * wv + li, ib_ = ia + 16;
+  const int32_t gia = c1 + r0 + (ia < nrow ? ia : 0), gib = c1 + r0 + (ib_ < nrow ? ib_ : 0);  // global labels of this lane's rows
+  // "transposed" bases: element index of Z(g_k, g_i) = baseT + g_k
+  int64_t bTa, bTb;
+  {
+    const int32_t oa = col_front[gia], ob = col_front[gib];
+    const int32_t ca = S.sn_start[oa], cb = S.sn_start[ob];
+    bTa = S.sn_loff[oa] + (int64_t)(gia - ca) * (S.n - ca) - ca;
+    bTb = S.sn_loff[ob] + (int64_t)(gib - cb) * (S.n - cb) - cb;
+  }
+  const double* YT = Ybuf + yoff[s];         // [u][128]
+  const int32_t b_off = 2 * lane < NB ? 2 * lane : 0;
+  const double* zsrc = zeros + 2 * lane;
+  struct Chunk { int64_t uN; int32_t md, kc, g0; };  // uN: element index of Z(0-th row label, first k) minus the row label: N address = uN + (k - g0) md + g_i
+  int32_t kd = wk.ka, kk0 = 0;
+  auto next_chunk = [&]() {
+    const int32_t cK = S.sn_start[kd], wK = S.sn_start[kd + 1] - cK;
+    Chunk c;
+    c.md = __builtin_amdgcn_readfirstlane(S.n - cK);
+    c.g0 = __builtin_amdgcn_readfirstlane(cK + kk0);
+    c.uN = uniform_i64(S.sn_loff[kd] + (int64_t)kk0 * c.md - cK);
+    c.kc = __builtin_amdgcn_readfirstlane(min(KBA, wK - kk0));
+    kk0 += KBA;
+    if (kk0 >= wK) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    double* Bs = smem + b * KBA * LDB;
+    const double* src = YT + (int64_t)(c.g0 - c1) * NB + b_off;
+#pragma unroll
+    for (int i = 0; i < KBA / 8; ++i) {
+      const int kr = wv + 8 * i;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(kr < c.kc ? src + (int64_t)kr * NB : zsrc), (lds_vptr)(Bs + kr * LDB), 16, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int sc, double (&ra)[4][2]) {
+    const int klast = (c.kc - 1) & ~3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kq = min(16 * sc + 4 * q, klast) + lk;      // k inside the chunk (lanes past a short chunk: B is zero there)
+      const int32_t gk = c.g0 + min(kq, c.kc - 1);
+      const int64_t eN = c.uN + (int64_t)(gk - c.g0) * c.md;
+      ra[q][0] = L[gia >= gk ? eN + gia : bTa + gk];
+      ra[q][1] = L[gib >= gk ? eN + gib : bTb + gk];
+    }
+  };
+  d4 acc16[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  if (wk.ka >= wk.kb || nrow <= 0) return;
+  double rA[2][4][2];
+  double bf[2][NJB];
+  auto ldB = [&](const double* Bc, int k4, double (&b)[NJB]) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
+  };
+  auto mma = [&](const double (&b)[NJB], double a0, double a1) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+      acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
+      acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
+    }
+  };
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  bool more = kd < wk.kb;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  ldB(smem, 0, bf[0]);
+  while (true) {
+    const double* Bc = smem + buf * KBA * LDB;
+    const double* Bn = smem + (buf ^ 1) * KBA * LDB;
+    bool more2 = false;
+    Chunk nn = nxt;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int sc = t >> 2, q = t & 3;
+      if (q == 0) {
+        if (sc < 3) load_A(cur, sc + 1, rA[(sc + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
+      }
+      if (t < 15) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.kb;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+      mma(bf[t & 1], rA[sc & 1][q][0], rA[sc & 1][q][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[s];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib == 0 ? ia : ib_, jc = 16 * jb + lk + 4 * r;
+        if (i < nrow && jc < w) unsafeAtomicAdd(&P[(int64_t)jc * m + w + r0 + i], -acc16[jb][ib][r]);
+      }
+}
+
+// rows [w, m) of every column of the panels of `fronts` <- 0 (before the atomic accumulation of Z_RC); one workgroup per
+// (front, column)
+__global__ __launch_bounds__(256) void k_sinv_zero(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L) {
+  const int32_t s = fronts[blockIdx.x];
+  const int32_t w = S.sn_start[s + 1] - S.sn_start[s];
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t j = blockIdx.y;
+  if (j >= w) return;
+  double* col = L + S.sn_loff[s] + (int64_t)j * m;
+  for (int32_t i = w + threadIdx.x; i < m; i += 256) col[i] = 0.0;
+}
+
 // diagonal block <- L11^-T L11^-1 (lower triangle; the strict upper part stays zero), one workgroup per front
 __global__ __launch_bounds__(256) void k_sinv_cc0(DevSym S, const int32_t* __restrict__ fronts, double* __restrict__ L,
                                                   const double* __restrict__ invD) {
@@ -2368,7 +2535,8 @@ __global__ __launch_bounds__(256) void k_sinv_cc0(DevSym S, const int32_t* __res
 // diagonal block -= Y_I^T Z_RC,I for one 128-row tile I of R (fp64 atomics: the tiles of a front add up in any order)
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_sinv_cc(DevSym S, const int32_t* __restrict__ tiles, double* L,
-                                                 const double* __restrict__ Ybuf, const int64_t* __restrict__ yoff) {
+                                                 const double* __restrict__ Ybuf, const int64_t* __restrict__ yoff,
+                                                 int32_t dense_first) {
   __shared__ __attribute__((aligned(16))) double As[KCS * LDA];  // [k = row of the tile][a] = Y[row][a]
   __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];  // [k][b] = Z_RC[row][b]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2397,7 +2565,7 @@ __global__ __launch_bounds__(256) void k_sinv_cc(DevSym S, const int32_t* __rest
       const int k = kh + 2 * x;
       const int32_t row = R0 + i0 + k;  // panel row
       const bool on = i0 + k < nrow && row >= w && cq < w;
-      As[k * LDA + cq] = on ? Y[(int64_t)cq * u + (row - w)] : 0.0;
+      As[k * LDA + cq] = on ? (s >= dense_first ? Y[(int64_t)(row - w) * NB + cq] : Y[(int64_t)cq * u + (row - w)]) : 0.0;
       Bs[k * LDB + cq] = on ? P[(int64_t)cq * m + row] : 0.0;
     }
     __syncthreads();
