@@ -308,6 +308,10 @@ def main():
         if rank == 0:
             import shutil
             shutil.rmtree(cache, ignore_errors=True)
+        # N processes of one node each hold the cohort and the analysis: drop what an evaluating rank no longer needs
+        sym.release_host_maps()
+        if rank != 0:
+            A = None  # (only rank 0 checks the residual against the matrix)
     t_sym = time.time() - t0
     info = sym.info()
     sym.set_profiling(True)
@@ -416,10 +420,12 @@ def main():
     X = dX[:, :r].cpu().numpy()
     s2 = sigma2_of(steps - 1)
     probe = [0, c, r - 1]  # first covariate column, the phenotype, the last simulated vector (last rank's share)
-    VX = s2[0] * (A @ X[:, probe]) + s2[-1] * X[:, probe]
-    for kq, Mq in enumerate(comps or []):
-        VX += s2[1 + kq] * (Mq @ X[:, probe])
-    resid = float(np.abs(VX - B_host[:, probe]).max() / np.abs(B_host[:, probe]).max())
+    resid = 0.0
+    if rank == 0:
+        VX = s2[0] * (A @ X[:, probe]) + s2[-1] * X[:, probe]
+        for kq, Mq in enumerate(comps or []):
+            VX += s2[1 + kq] * (Mq @ X[:, probe])
+        resid = float(np.abs(VX - B_host[:, probe]).max() / np.abs(B_host[:, probe]).max())
 
     if rank == 0:
         K = steps

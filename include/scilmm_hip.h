@@ -105,6 +105,11 @@ int scilmm_order(int32_t n, const int64_t* indptr, const int32_t* indices, int32
 int scilmm_fill_count(int32_t n, const int64_t* indptr, const int32_t* indices, const int32_t* perm, int64_t* nnzL,
                       double* flops, int32_t* max_colcount);
 
+/* Frees the host copies of the value-assembly maps (asm_dst, pat_row, val_slot / val_src: 13 GB at the 1M config) once the
+ * values are in HBM and the device plan exists; afterwards scilmm_values_upload and the corresponding scilmm_symbolic_get
+ * names are no longer available on this handle.  For processes that only evaluate (8 ranks of one node each hold a copy). */
+int scilmm_symbolic_release_host_maps(scilmm_symbolic* sym);
+
 /* --- values: one upload per A_k replaces the per-evaluation CSR arithmetic of matrices_weighted_sum
  * (SparseCholesky.py:55-59).  data_k is the CSR data array matching indptr[k]/indices[k]. */
 int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k);

@@ -59,7 +59,7 @@ class Timing(C.Structure):
 # every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "scilmm_symbolic_create", "scilmm_symbolic_info", "scilmm_symbolic_get", "scilmm_symbolic_error",
-    "scilmm_symbolic_free", "scilmm_symbolic_save", "scilmm_symbolic_load", "scilmm_values_upload", "scilmm_factorize", "scilmm_refactorize",
+    "scilmm_symbolic_free", "scilmm_symbolic_save", "scilmm_symbolic_load", "scilmm_symbolic_release_host_maps", "scilmm_values_upload", "scilmm_factorize", "scilmm_refactorize",
     "scilmm_refactorize_async", "scilmm_factor_wait", "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
     "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
@@ -103,6 +103,7 @@ def lib():
     L.scilmm_symbolic_free.restype = None
     L.scilmm_symbolic_save.argtypes = [vp, C.c_char_p, C.c_uint64]
     L.scilmm_symbolic_load.argtypes = [C.c_char_p, C.c_uint64, P(vp)]
+    L.scilmm_symbolic_release_host_maps.argtypes = [vp]
     L.scilmm_values_upload.argtypes = [vp, i32, vp]
     L.scilmm_factorize.argtypes = [vp, vp, P(vp), P(i32)]
     L.scilmm_refactorize.argtypes = [vp, vp, P(i32)]

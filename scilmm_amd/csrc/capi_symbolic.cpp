@@ -60,6 +60,18 @@ int scilmm_symbolic_load(const char* path, uint64_t key, scilmm_symbolic** out) 
   return SCILMM_OK;
 }
 
+int scilmm_symbolic_release_host_maps(scilmm_symbolic* h) {
+  if (!h || !h->S) return SCILMM_ERR_ARG;
+  if (!h->device) return SCILMM_ERR_STATE;  // the device plan reads them: call after the first numeric call
+  scilmm::Symbolic& S = *h->S;
+  std::vector<int64_t>().swap(S.asm_dst);
+  std::vector<int32_t>().swap(S.pat_row);
+  for (auto& v : S.val_slot) std::vector<int64_t>().swap(v);
+  for (auto& v : S.val_src) std::vector<int64_t>().swap(v);
+  h->maps_released = true;
+  return SCILMM_OK;
+}
+
 int scilmm_symbolic_info(const scilmm_symbolic* h, scilmm_info* info) {
   if (!h || !h->S || !info) return SCILMM_ERR_ARG;
   const Symbolic& S = *h->S;

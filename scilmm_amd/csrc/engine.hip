@@ -1116,7 +1116,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* eti = tune_env("SCILMM_TARGET_ITEMS");
     const char* emn = tune_env("SCILMM_MIN_ITEM");
     const char* edi = tune_env("SCILMM_DENSE_ITEMS");
-    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 2048);  // k_dense_b items per launch (target)
+    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 1024);  // k_dense_b items per launch (target; round 3 with k_dense_b, 300k: 384 / 512 / 768 / 1024 / 2048 / 3072 = 1373 / 1369 / 1365 / 1357 / 1384 / 1407 ms, 1M: 27.0 vs 27.35 s)
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -1626,8 +1626,8 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
@@ -1774,10 +1774,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     for (int64_t o = 0; o < cnt; o += max_groups(512)) {
       const unsigned c = (unsigned)std::min<int64_t>(cnt - o, max_groups(512));
       if (D->front_bits == 32)
-        hipLaunchKernelGGL(k_dense32, dim3(c), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
-                           S.dense_first, dw + o, fac->L, scratch_half);
+        hipLaunchKernelGGL(k_dense_b<true>, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
+                           fac->L, scratch_half, (const double*)D->d_zeros);
       else
-        hipLaunchKernelGGL(k_dense_b, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
+        hipLaunchKernelGGL(k_dense_b<false>, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
                            fac->L, scratch_half, (const double*)D->d_zeros);
       launches++;
     }
@@ -2459,6 +2459,10 @@ int scilmm_values_upload(scilmm_symbolic* sym, int32_t k, const double* data_k) 
   DevGuard guard(sym);
   const Symbolic& S = *sym->S;
   if (k < 0 || k >= S.K) return SCILMM_ERR_ARG;
+  if (sym->maps_released) {
+    sym->err = "scilmm_values_upload: the value-assembly maps of this handle were released";
+    return SCILMM_ERR_STATE;
+  }
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;

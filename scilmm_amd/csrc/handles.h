@@ -15,4 +15,5 @@ struct scilmm_symbolic {
   void* comm_stream = nullptr;
   int (*comm_fn)(void* ctx, int32_t op, int32_t buffer, int64_t offset, int64_t count, int32_t root) = nullptr;
   void* comm_ctx = nullptr;
+  bool maps_released = false;          // scilmm_symbolic_release_host_maps: no further value uploads
 };

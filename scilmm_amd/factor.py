@@ -106,12 +106,19 @@ class Symbolic(object):
         check(lib().scilmm_values_download(self._h, k, ptr(out)), self._h)
         return out
 
+    def release_host_maps(self):
+        """Free the host copies of the value-assembly maps and of the uploaded values (a process that only evaluates does not
+        need them: 13 + 7 GB at the 1M config); ``set_values`` is no longer available afterwards."""
+        check(lib().scilmm_symbolic_release_host_maps(self._h), self._h)
+        self._data = [None] * self.K
+
     def set_values(self, k, data):
         """Replace the values of matrix k (same pattern)."""
         data = np.ascontiguousarray(data, dtype=np.float64)
-        if data.shape != self._data[k].shape:
-            raise ValueError("value array does not match the analysed pattern")
-        self._data[k] = data
+        if self._data[k] is not None:
+            if data.shape != self._data[k].shape:
+                raise ValueError("value array does not match the analysed pattern")
+            self._data[k] = data
         check(lib().scilmm_values_upload(self._h, k, ptr(data)), self._h)
 
     def __del__(self):

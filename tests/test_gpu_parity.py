@@ -92,6 +92,22 @@ def test_refactorize_reuses_symbolic():
     assert abs(ld1 - f.logdet()) > 1e-3
 
 
+def test_released_host_maps_keep_the_resident_values_usable():
+    """scilmm_symbolic_release_host_maps: evaluations go on from the values in HBM; a further upload is refused."""
+    from oracle import oracle as O
+    from scilmm_amd._lib import ScilmmError
+    A = random_spd(300, 0.05, 21)
+    I = sp.identity(300, format="csr")
+    sym = _engine([A, I])
+    f = sym.factorize([0.5, 0.5])
+    sym.release_host_maps()
+    f.refactorize([0.3, 0.8])
+    o = O.OracleFactor((0.3 * A + 0.8 * I).tocsr(), f.P())
+    assert abs(f.logdet() - o.logdet()) < TOL * abs(o.logdet())
+    with pytest.raises(ScilmmError):
+        sym.set_values(0, A.data)
+
+
 def test_user_permutation_and_L_uniqueness():
     from oracle import oracle as O
     A = random_spd(90, 0.15, 13)

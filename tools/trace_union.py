@@ -1,6 +1,6 @@
 """Interval union of one kernel's launches in a rocprofv3 kernel trace.
 
-    python tools/trace_union.py <kernel_trace.csv> [name-regex, default k_dense_a] [--by-step N]
+    python tools/trace_union.py <kernel_trace.csv> [name-regex, default k_dense_b] [--by-step N]
 
 rocprofv3 --kernel-trace writes one row per dispatch with Start_Timestamp / End_Timestamp (ns).  When two launches of
 the dominant kernel overlap on the engine's two look-ahead streams, the SUM of their durations (what --stats averages)
@@ -16,7 +16,7 @@ def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     path = sys.argv[1]
-    pat = re.compile(sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "k_dense_a")
+    pat = re.compile(sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "k_dense_b")
     iv = []
     with open(path, newline="") as fh:
         rd = csv.DictReader(fh)
