@@ -270,7 +270,17 @@ def main():
             comps = A[1:]
             A = A[0]
     else:
-        shm = "/dev/shm/scilmm_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), args.workload)
+        # (hand-off directory: memory-backed /dev/shm when it has the room -- 26 GB at the 1M config -- else the temp directory)
+        need = {"1m": 40e9, "300k": 8e9}.get(args.workload, 2e9)
+        import shutil
+        import tempfile
+        roots = [d for d in ("/dev/shm", os.environ.get("TMPDIR") or tempfile.gettempdir(), os.getcwd())
+                 if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need]
+        if not roots:
+            raise SystemExit("bench.py: no directory with %.0f GB free for the rank hand-off files" % (need / 1e9))
+        roots = roots[:1]
+        dist.broadcast_object_list(roots, src=0)  # (rank 0's choice: free space is a moving number)
+        shm = "%s/scilmm_bench_%s_%s" % (roots[0], os.environ.get("MASTER_PORT", "0"), args.workload)
         if rank == 0:
             A, C, y = build_problem(args.workload, seed=seed)
             np.save(shm + "_indptr.npy", A.indptr); np.save(shm + "_indices.npy", A.indices)
@@ -298,7 +308,7 @@ def main():
     else:
         from scilmm_amd.dist import HipChainEngine
         # one analysis per NODE: rank 0 analyses the pattern and leaves its image in /dev/shm, the others load it
-        cache = "/dev/shm/scilmm_bench_sym_%s" % os.environ.get("MASTER_PORT", "0")
+        cache = "%s/scilmm_bench_sym_%s" % (roots[0], os.environ.get("MASTER_PORT", "0"))
         if rank == 0:
             Symbolic([A, sp.identity(n, format="csr")], upload=False, cache=cache)
         dist.barrier()
@@ -306,7 +316,6 @@ def main():
         sym = eng.sym
         dist.barrier()
         if rank == 0:
-            import shutil
             shutil.rmtree(cache, ignore_errors=True)
         # N processes of one node each hold the cohort and the analysis: drop what an evaluating rank no longer needs
         sym.release_host_maps()

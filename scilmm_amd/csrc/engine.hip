@@ -1116,6 +1116,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* eti = tune_env("SCILMM_TARGET_ITEMS");
     const char* emn = tune_env("SCILMM_MIN_ITEM");
     const char* edi = tune_env("SCILMM_DENSE_ITEMS");
+    const char* edf = getenv("SCILMM_DENSE_FILL");
+    const int64_t dense_fill = edf ? atoll(edf) : 256;  // workgroups per round the dense item counts are fitted to (0: no fitting)
     const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 1024);  // k_dense_b items per launch (target; round 3 with k_dense_b, 300k: 384 / 512 / 768 / 1024 / 2048 / 3072 = 1373 / 1369 / 1365 / 1357 / 1384 / 1407 ms, 1M: 27.0 vs 27.35 s)
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
@@ -1217,26 +1219,6 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           // dense_items items per launch: every item writes two 128 KB slabs that k_reduce reads back, so few long
           // items beat many short ones as long as the launch still fills the chip a few times over
           const int64_t npairs = (ntl + 1) / 2;
-          const int64_t want = std::max<int64_t>(1, (dense_items + npairs / 2) / npairs);
-          auto build = [&](int32_t lo, int32_t hi, std::vector<std::pair<int32_t, int32_t>>& out) -> int64_t {
-            out.clear();
-            std::vector<std::pair<int32_t, int32_t>> runs;
-            const int64_t total = active_runs(jj, lo, hi, runs);
-            if (total == 0) return 0;
-            const int64_t nseg = std::min<int64_t>(std::min<int64_t>(64, total), want);
-            for (auto& r : runs) {
-              const int64_t len = r.second - r.first;
-              const int64_t ns_r = std::max<int64_t>(1, std::min<int64_t>(len, (nseg * len + total / 2) / total));
-              for (int64_t q = 0; q < ns_r; ++q) {
-                const int32_t a = r.first + (int32_t)(len * q / ns_r), b = r.first + (int32_t)(len * (q + 1) / ns_r);
-                if (b > a) out.push_back({a, b});
-              }
-            }
-            return total;
-          };
-          const int64_t act_e = dist ? 0 : build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
-          dense_pairs_all += dist ? dcnt_l : jj;
-          dense_pairs_kept += act_e + act_l;
           // rows of the target that NO active descendant reaches receive nothing but padding: their tile pairs get no
           // items (below the dense region the fronts of one side branch do not reach the columns of the others, nor
           // the part of the region sorted to its start)
@@ -1262,6 +1244,49 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
               pair_on[(size_t)pq] = need ? 1 : 0;
             }
           }
+          int64_t np_on = 0;
+          for (uint8_t v : pair_on) np_on += v;
+          // K segments: about dense_items items per launch, and -- when the plan may choose (dense_fill) -- a count that
+          // fills the last round of workgroups: the items of a launch last about equally long, so I items on 256 CUs take
+          // ceil(I / 256) rounds whatever I is (1M config: 1100 items = 4.3 rounds paid as 5)
+          const int64_t want = std::max<int64_t>(1, (dense_items + std::max<int64_t>(1, np_on) / 2) / std::max<int64_t>(1, np_on));
+          std::vector<std::pair<int32_t, int32_t>> runs;
+          auto cut_runs = [&](int64_t total, int64_t nseg, std::vector<std::pair<int32_t, int32_t>>* out) -> int64_t {
+            int64_t cnt = 0;
+            for (auto& r : runs) {
+              const int64_t len = r.second - r.first;
+              const int64_t ns_r = std::max<int64_t>(1, std::min<int64_t>(len, (nseg * len + total / 2) / total));
+              for (int64_t q = 0; q < ns_r; ++q) {
+                const int32_t a = r.first + (int32_t)(len * q / ns_r), b = r.first + (int32_t)(len * (q + 1) / ns_r);
+                if (b > a) {
+                  ++cnt;
+                  if (out) out->push_back({a, b});
+                }
+              }
+            }
+            return cnt;
+          };
+          auto build = [&](int32_t lo, int32_t hi, std::vector<std::pair<int32_t, int32_t>>& out) -> int64_t {
+            out.clear();
+            const int64_t total = active_runs(jj, lo, hi, runs);
+            if (total == 0) return 0;
+            const int64_t cap = std::min<int64_t>(64, total);
+            int64_t nseg = std::min(cap, want);
+            if (dense_fill && np_on > 0) {
+              double best = -1.0;
+              for (int64_t ns = std::max<int64_t>(1, want * 2 / 3); ns <= std::min(cap, want * 3 / 2 + 1); ++ns) {
+                const int64_t items = np_on * cut_runs(total, ns, nullptr);
+                const int64_t rounds = (items + dense_fill - 1) / dense_fill;
+                const double score = (double)items / (double)(rounds * dense_fill) - 0.02 * std::fabs((double)(ns - want)) / (double)want;
+                if (score > best) { best = score; nseg = ns; }
+              }
+            }
+            cut_runs(total, nseg, &out);
+            return total;
+          };
+          const int64_t act_e = dist ? 0 : build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
+          dense_pairs_all += dist ? dcnt_l : jj;
+          dense_pairs_kept += act_e + act_l;
           for (uint8_t v : pair_on) { dense_tiles_all += 1; dense_tiles_kept += v; }
           if (dist) own_pair_on[(size_t)jj] = pair_on;
           total_e += ntl * dunit * act_e;
@@ -1626,8 +1651,8 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   D->attrs_set = true;
@@ -1774,10 +1799,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     for (int64_t o = 0; o < cnt; o += max_groups(512)) {
       const unsigned c = (unsigned)std::min<int64_t>(cnt - o, max_groups(512));
       if (D->front_bits == 32)
-        hipLaunchKernelGGL(k_dense_b<true>, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
-                           fac->L, scratch_half, (const double*)D->d_zeros);
+        hipLaunchKernelGGL(k_dense32, dim3(c), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
+                           S.dense_first, dw + o, fac->L, scratch_half);
       else
-        hipLaunchKernelGGL(k_dense_b<false>, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
+        hipLaunchKernelGGL(k_dense_b, dim3(c), dim3(512), sizeof(double) * (size_t)(2 * KBA * LDB), stream, D->v, S.dense_first, dw + o,
                            fac->L, scratch_half, (const double*)D->d_zeros);
       launches++;
     }

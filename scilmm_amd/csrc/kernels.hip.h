@@ -512,9 +512,6 @@ typedef const __attribute__((address_space(1))) void* gl_vptr;
 #ifndef SCILMM_DENSE_B_SG
 #define SCILMM_DENSE_B_SG 1   // 1: interleave one LDS read with four MFMAs (sched_group_barrier); 0: leave it to the scheduler
 #endif
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-template <bool F32>
 __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
                                                     double* __restrict__ L, double* __restrict__ scratch,
                                                     const double* __restrict__ zeros) {
@@ -543,10 +540,8 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
     c.md = __builtin_amdgcn_readfirstlane(S.n - c0d);
     c.Pd = L + uniform_i64(S.sn_loff[d] + (int64_t)kk0 * c.md + (c0j - c0d));
     c.kc = __builtin_amdgcn_readfirstlane(min(KBA, wd - kk0));
-    if constexpr (!F32) {
-      c.v0 = (uint32_t)(lk * c.md + ra0) * 8u;  // byte offsets of this lane's rows in the k-column lk of a 4-deep block
-      c.v1 = (uint32_t)(lk * c.md + ra1) * 8u;
-    }
+    c.v0 = (uint32_t)(lk * c.md + ra0) * 8u;  // byte offsets of this lane's rows in the k-column lk of a 4-deep block
+    c.v1 = (uint32_t)(lk * c.md + ra1) * 8u;
     kk0 += KBA;
     if (kk0 >= wd) { kk0 = 0; ++kd; }
     return c;
@@ -561,13 +556,11 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
   };
   auto load_A = [&](const Chunk& c, int s, double (&ra)[4][2]) {
     const int klast = (c.kc - 1) & ~3;
-    // (fp32 form: the offsets are recomputed here instead of living in registers for three chunks)
-    const uint32_t v0 = F32 ? (uint32_t)(lk * c.md + ra0) * 8u : c.v0, v1 = F32 ? (uint32_t)(lk * c.md + ra1) * 8u : c.v1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double* sp = c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md;  // wave-uniform
-      ra[q][0] = ld_off(sp, v0);
-      ra[q][1] = ld_off(sp, v1);
+      ra[q][0] = ld_off(sp, c.v0);
+      ra[q][1] = ld_off(sp, c.v1);
     }
   };
   d4 acc16[NJB][2];
@@ -575,46 +568,17 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
   for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
   if (wk.k0 >= wk.k1) return;
   double rA[2][4][2];
-  typedef typename std::conditional<F32, float, double>::type frag_t;
-  frag_t bf[2][NJB];
-  // F32: one set of fp32 accumulators takes 16 k-steps (64 k), then is folded into the fp64 accumulators (the register
-  // file holds 256 per wave at two waves per SIMD: 128 fp64 + 64 fp32 accumulators leave room for one set only).  The two
-  // waves of a SIMD fold at DIFFERENT k-steps (wave parity), so one of them always has products for the matrix pipe.
-  f4 c32[1][F32 ? NJB : 1][2];
-  const bool fold_phase = (wv >> 2) & 1;
-  if constexpr (F32) {
+  double bf[2][NJB];
+  auto ldB = [&](const double* Bc, int k4, double (&b)[NJB]) {
 #pragma unroll
-    for (int a = 0; a < NJB; ++a) { c32[0][a][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[0][a][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
-  }
-  auto ldB = [&](const double* Bc, int k4, frag_t (&b)[NJB]) {
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb) b[jb] = (frag_t)Bc[(k4 + lk) * LDB + 16 * jb + li];
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
   };
-  float raf[4][2];  // F32: the current sub-chunk's A fragments, rounded when they arrived
-  auto mma = [&](const frag_t (&b)[NJB], frag_t a0, frag_t a1) {
-    if constexpr (F32) {
+  auto mma = [&](const double (&b)[NJB], double a0, double a1) {
 #pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
-        c32[0][jb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[jb], a0, c32[0][jb][0], 0, 0, 0);
-        c32[0][jb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[jb], a1, c32[0][jb][1], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
-        acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
-        acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
-      }
+    for (int jb = 0; jb < NJB; ++jb) {
+      acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
+      acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
     }
-  };
-  auto fold = [&](int h) {
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc16[jb][ib][r] += (double)c32[h][jb][ib][r];
-        c32[h][jb][ib] = (f4){0.f, 0.f, 0.f, 0.f};
-      }
   };
   Chunk cur = next_chunk();
   issue_B(cur, 0);
@@ -628,7 +592,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
-  if constexpr (!F32) ldB(smem, 0, bf[0]);
+  ldB(smem, 0, bf[0]);
   while (true) {
     const double* Bc = smem + buf * KBA * LDB;
     const double* Bn = smem + (buf ^ 1) * KBA * LDB;
@@ -639,38 +603,26 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
       const int s = t >> 2, q = t & 3;
       if (q == 0) {
         // the A fragments of the next sub-chunk (or of the next chunk's first one): one sub-chunk of MFMA time ahead
-        if constexpr (F32) {
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) { raf[qq][0] = (float)rA[0][qq][0]; raf[qq][1] = (float)rA[0][qq][1]; }
-          if (s < 3) load_A(cur, s + 1, rA[0]);
-          else if (more) load_A(nxt, 0, rA[0]);
-        } else {
-          if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
-          else if (more) load_A(nxt, 0, rA[0]);
-        }
+        if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
       }
-      if constexpr (F32) ldB(Bc, 4 * t, bf[0]);   // (no fragment prefetch in the fp32 form: the registers hold two accumulator sets)
-      if (!F32 && t < 15) {
+      if (t < 15) {
         ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
-      } else if (t == 15 && more) {
+      } else if (more) {
         // chunk boundary: every wave has READ its last fragments of Bc (they are in registers) and the copy of the next
         // chunk has landed -- after this barrier Bn may be read and Bc overwritten
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if constexpr (!F32) ldB(Bn, 0, bf[0]);
+        ldB(Bn, 0, bf[0]);
         more2 = kd < wk.k1;
         if (more2) {
           nn = next_chunk();
           issue_B(nn, buf);
         }
       }
-      if constexpr (F32) {
-        if ((t == 0 && !fold_phase) || (t == 8 && fold_phase)) fold(0);
-      }
-      if constexpr (F32) mma(bf[0], raf[q][0], raf[q][1]);
-      else mma(bf[t & 1], rA[s & 1][q][0], rA[s & 1][q][1]);
+      mma(bf[t & 1], rA[s & 1][q][0], rA[s & 1][q][1]);
 #if SCILMM_DENSE_B_SG
-      if (!F32 && t < 15) {
+      if (t < 15) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read (two fragments) ...
@@ -686,7 +638,6 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
     more = more2;
     buf ^= 1;
   }
-  if constexpr (F32) fold(0);
   double* P = L + S.sn_loff[j];
 #pragma unroll
   for (int jb = 0; jb < NJB; ++jb)
@@ -694,8 +645,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // (fp32 MFMA result layout: lane l, register r holds D[M = 4 (l >> 4) + r][N = l & 15]; fp64: M = (l >> 4) + 4 r)
-        const int i = ib == 0 ? ia : ib_, jc = F32 ? 16 * jb + 4 * lk + r : 16 * jb + lk + 4 * r;
+        const int i = ib == 0 ? ia : ib_, jc = 16 * jb + lk + 4 * r;
         const double v = acc16[jb][ib][r];
         const int h = i >> 7;
         const int32_t slot = h ? wk.slot1 : wk.slot0;
@@ -718,6 +668,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
 // scilmm_amd.factor.Factor repairs the solves by iterative refinement against the exact V (fp64 SpMM on the device).
 // Same work items, slabs and epilogue contract as k_dense.  fp32 MFMA result layout (differs from the f64 form):
 // lane l, register r holds D[M = 4 (l >> 4) + r][N = l & 15].
+typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int LDA2F = DTR + 16;   // floats; == 16 mod 64: the four k rows of a fragment read hit disjoint banks
 constexpr int LDBF = NB + 16;
 

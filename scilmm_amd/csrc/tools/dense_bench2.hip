@@ -62,8 +62,8 @@ int main(int argc, char** argv) {
   double* scratch;
   CK(hipMalloc(&scratch, sizeof(double) * (size_t)slot * TM * NB));
   CK(hipFuncSetAttribute((const void*)k_dense_a, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  CK(hipFuncSetAttribute((const void*)k_dense_b<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  CK(hipFuncSetAttribute((const void*)k_dense_b<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_dense_b, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_dense_f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   double* zeros;
   CK(hipMalloc(&zeros, 2048));
@@ -83,15 +83,15 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 4; ++rep) {
       hipEventRecord(e0);
       if (which == 0) hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
-      else if (which == 1) hipLaunchKernelGGL(k_dense_b<false>, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
-      else if (which == 2) hipLaunchKernelGGL(k_dense_b<true>, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      else if (which == 1) hipLaunchKernelGGL(k_dense_b, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      else if (which == 2) hipLaunchKernelGGL(k_dense_f, dim3((unsigned)work.size()), dim3(512), dense_f_lds, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else hipLaunchKernelGGL(k_dense32, dim3((unsigned)work.size()), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), 0, S, 0, d_work, L, scratch);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       CK(hipGetLastError());
-      if (rep) printf("%s, %s operands: %.3f ms -> %.2f TFLOP/s\n", which == 0 ? "k_dense_a" : which == 1 ? "k_dense_b<fp64>" : which == 2 ? "k_dense_b<fp32 products>" : "k_dense32 (round 2)", fill ? "random" : "zero", ms, flops / ms / 1e9);
+      if (rep) printf("%s, %s operands: %.3f ms -> %.2f TFLOP/s\n", which == 0 ? "k_dense_a" : which == 1 ? "k_dense_b" : which == 2 ? "k_dense_f (fp32 products)" : "k_dense32 (round 2)", fill ? "random" : "zero", ms, flops / ms / 1e9);
     }
   }
   {
@@ -102,19 +102,19 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
     CK(hipMemcpy(r0.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
     CK(hipMemset(scratch, 0, sizeof(double) * ns));
-    hipLaunchKernelGGL(k_dense_b<false>, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+    hipLaunchKernelGGL(k_dense_b, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
     CK(hipMemcpy(r1.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
     double mx = 0, ref = 0;
     for (size_t i = 0; i < ns; ++i) { mx = std::max(mx, std::fabs(r0[i] - r1[i])); ref = std::max(ref, std::fabs(r0[i])); }
     printf("k_dense_b vs k_dense_a: max |difference| of the slabs %.3g (largest entry %.3g)\n", mx, ref);
     for (int v = 0; v < 2; ++v) {
       CK(hipMemset(scratch, 0, sizeof(double) * ns));
-      if (v == 0) hipLaunchKernelGGL(k_dense_b<true>, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      if (v == 0) hipLaunchKernelGGL(k_dense_f, dim3((unsigned)work.size()), dim3(512), dense_f_lds, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else hipLaunchKernelGGL(k_dense32, dim3((unsigned)work.size()), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), 0, S, 0, d_work, L, scratch);
       CK(hipMemcpy(r1.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
       mx = 0;
       for (size_t i = 0; i < ns; ++i) mx = std::max(mx, std::fabs(r0[i] - r1[i]));
-      printf("%s vs fp64: max |difference| of the slabs %.3g (largest entry %.3g)\n", v ? "k_dense32 (round 2)" : "k_dense_b<fp32 products>", mx, ref);
+      printf("%s vs fp64: max |difference| of the slabs %.3g (largest entry %.3g)\n", v ? "k_dense32 (round 2)" : "k_dense_f (fp32 products)", mx, ref);
     }
   }
   return 0;

@@ -1154,4 +1154,214 @@ __global__ __launch_bounds__(512, 1) void k_dense_a(DevSym S, int32_t dense_firs
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// k_dense_f (RETIRED before it shipped: 70 TFLOP/s alone against k_dense32's 83, see the note at the end): the fp32-product
+// dense-tail update, round 3 -- k_dense_b's operand streams with the products on the fp32 matrix
+// pipe.  On gfx950 v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and measurably shares its issue time with the
+// double-precision vector instructions of the same wave pair, so the kernel is organised around issuing as few of those
+// as possible per k-step of 16 products (k_dense32 above: 3 conversions + 32 fold instructions per k-step, 83 TFLOP/s
+// alone; the straightforward fp32 form of k_dense_b, every wave converting the B fragments it reads: 10 + 8, 84 TFLOP/s):
+//  * B: the 32 k-rows of a chunk arrive as fp64 by LDS-DMA (two staging buffers, copy issued three chunks ahead) and are
+//    rounded to an fp32 image ONCE per workgroup, each wave converting exactly the k-rows it copied itself (no barrier
+//    between copy and conversion): 1 conversion per lane and k-step.  The fragments are then 4-byte LDS reads, prefetched
+//    one k-step ahead as in k_dense_b.
+//  * A: straight from the panel into registers one 16-deep sub-chunk ahead (k_dense_b's addressing), rounded when they
+//    arrive: 2 conversions per k-step.
+//  * sums: fp32 accumulators take SCILMM_DENSE_F_FOLD chunks (64 k by default), then are folded into the fp64 accumulators
+//    that live across the item (8 instructions per k-step); the product after a fold starts from a zero C operand instead
+//    of cleared registers.  The two waves of a SIMD fold in different chunks, so one of them always feeds the matrix pipe.
+// Same work items, slabs and epilogue contract as k_dense_b; error model as k_dense32 with 64 instead of 16 products per
+// fp32 sum (measured against the fp64 kernel on random operands: 9e-5 against 2e-5 absolute at entries of 2e3).
+constexpr int KF = 32;      // k-rows per chunk
+constexpr int DROW = NB;    // doubles per k-row of a staging buffer (read back only by the lane that the DMA wrote for)
+#ifndef SCILMM_DENSE_F_FOLD
+#define SCILMM_DENSE_F_FOLD 2
+#endif
+constexpr size_t dense_f_lds = sizeof(double) * 2 * KF * DROW + sizeof(float) * 2 * KF * LDBF;
+
+__global__ __launch_bounds__(512, 1) void k_dense_f(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, double* __restrict__ scratch,
+                                                    const double* __restrict__ zeros) {
+  static_assert(NB == 128 && DTR == 256 && (SCILMM_DENSE_F_FOLD & (SCILMM_DENSE_F_FOLD - 1)) == 0, "k_dense_f: 8 waves x 32 rows");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Dbuf = smem;                              // [2][KF][DROW]  fp64 k-rows as copied
+  float* Fimg = (float*)(smem + 2 * KF * DROW);     // [2][KF][LDBF]  their fp32 image
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  const int32_t ia = 32 * wv + li, ib_ = ia + 16;
+  const int32_t ra0 = R0 + (ia < nrow ? ia : 0);
+  const int32_t ra1 = R0 + (ib_ < nrow ? ib_ : 0);
+  const int32_t b_off = 2 * lane < wj ? 2 * lane : 0;
+  const double* zsrc = zeros + 2 * lane;
+  if (wk.k0 >= wk.k1) return;
+  struct Chunk { const double* Pd; int32_t md; int kc; };
+  struct Iter { int32_t kd, kk0; };
+  auto next_chunk = [&](Iter& it) {
+    const int32_t d = dense_first + it.kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    Chunk c;
+    c.md = __builtin_amdgcn_readfirstlane(S.n - c0d);
+    c.Pd = L + uniform_i64(S.sn_loff[d] + (int64_t)it.kk0 * c.md + (c0j - c0d));
+    c.kc = __builtin_amdgcn_readfirstlane(min(KF, wd - it.kk0));
+    it.kk0 += KF;
+    if (it.kk0 >= wd) { it.kk0 = 0; ++it.kd; }
+    return c;
+  };
+  Iter it_c{wk.k0, 0}, it_d{wk.k0, 0};  // the same chunk sequence twice: multiplied / copied (three chunks ahead)
+  auto dma = [&](int b) {
+    if (it_d.kd >= wk.k1) return;
+    const Chunk c = next_chunk(it_d);
+    double* Db = Dbuf + b * KF * DROW;
+#pragma unroll
+    for (int i = 0; i < KF / 8; ++i) {
+      const int kr = wv + 8 * i;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(kr < c.kc ? c.Pd + (int64_t)kr * c.md + b_off : zsrc), (lds_vptr)(Db + kr * DROW), 16, 0, 0);
+    }
+  };
+  auto convert = [&](int b) {  // this wave's k-rows of staging buffer b -> image b
+    const double* Db = Dbuf + b * KF * DROW;
+    float* Fi = Fimg + b * KF * LDBF;
+#pragma unroll
+    for (int h = 0; h < KF / 16; ++h) {  // (two k-rows at a time: the registers are all but full)
+      d2 v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = *(const d2*)(Db + (wv + 8 * (2 * h + i)) * DROW + 2 * lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *(f2*)(Fi + (wv + 8 * (2 * h + i)) * LDBF + 2 * lane) = (f2){(float)v[i][0], (float)v[i][1]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  double rA[4][2];
+  float raf[4][2];
+  auto load_A = [&](const Chunk& c, int s) {
+    const int klast = (c.kc - 1) & ~3;
+    const uint32_t v0 = (uint32_t)(lk * c.md + ra0) * 8u, v1 = (uint32_t)(lk * c.md + ra1) * 8u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* sp = c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md;  // wave-uniform
+      rA[q][0] = ld_off(sp, v0);
+      rA[q][1] = ld_off(sp, v1);
+    }
+  };
+  d4 acc[NJB][2];
+  f4 c32[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) {
+    acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0};
+    c32[a][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  float bf[2][NJB];
+  auto ldB = [&](const float* Fc, int k4, float (&b)[NJB]) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Fc[(k4 + lk) * LDBF + 16 * jb + li];
+  };
+  auto fold = [&]() {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][ib][r] += (double)c32[jb][ib][r];
+  };
+  const int fold_phase = (wv >> 2) & (SCILMM_DENSE_F_FOLD - 1);
+  Chunk cur = next_chunk(it_c);
+  dma(0);
+  dma(1);
+  load_A(cur, 0);
+  bool more = it_c.kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) nxt = next_chunk(it_c);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  convert(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  dma(0);
+  __syncthreads();
+  ldB(Fimg, 0, bf[0]);
+  int cidx = 0;
+  while (true) {
+    const float* Fc = Fimg + (cidx & 1) * KF * LDBF;
+    const float* Fn = Fimg + ((cidx + 1) & 1) * KF * LDBF;
+    bool more2 = false;
+    Chunk nn = nxt;
+    const bool do_fold = (cidx & (SCILMM_DENSE_F_FOLD - 1)) == fold_phase;
+#pragma unroll
+    for (int t = 0; t < KF / 4; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) { raf[qq][0] = (float)rA[qq][0]; raf[qq][1] = (float)rA[qq][1]; }
+        if (s == 1 && more) {
+          // the next chunk's fp32 image (its copy was issued two chunks ago), then the copy of the chunk three ahead into
+          // the staging buffer just read
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          convert((cidx + 1) & 1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma((cidx + 1) & 1);
+        }
+        if (s == 0) load_A(cur, 1);
+        else if (more) load_A(nxt, 0);
+      }
+      if (t < KF / 4 - 1) {
+        ldB(Fc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        // chunk boundary: every wave has read its last fragments of this image and written its rows of the next one
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Fn, 0, bf[0]);
+        more2 = it_c.kd < wk.k1;
+        if (more2) nn = next_chunk(it_c);
+      }
+      if (t == 0 && do_fold) {
+        fold();
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) { c32[jb][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[jb][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
+      }
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        c32[jb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], raf[q][0], c32[jb][0], 0, 0, 0);
+        c32[jb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], raf[q][1], c32[jb][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    ++cidx;
+  }
+  fold();
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib == 0 ? ia : ib_, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+        const double v = acc[jb][ib][r];
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+        }
+      }
+}
+
+// Why k_dense_f is here: profiles/r3_mfma_f32_mix.txt (csrc/tools/mfma_f32_mix.hip) shows that the instruction mix is not
+// what holds the fp32-product kernels at half of the fp32 matrix rate (16 MFMAs + LDS fragments + a fold every 16 k-steps:
+// 135 of 155 TFLOP/s; a fold every 4 k-steps, k_dense32's period: 107), so removing conversions and folds bought nothing,
+// and the shorter chunks (a barrier per 32 k) cost 15 %.  What the three fp32 forms share is the fp64 OPERAND stream: a
+// 256 x 128 tile reads 32 flop per HBM byte, i.e. 2.7 TB/s at 83 TFLOP/s in 128-byte pieces -- the fp32 forms are bound by
+// that stream, not by the matrix pipe.
+
 }  // namespace scilmm
