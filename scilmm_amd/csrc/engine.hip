@@ -2180,6 +2180,30 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     const int rc = std::min<int>(RPMAX, r - cbeg);
     const int rp = rp_of(rc);
     const unsigned gy = (unsigned)((rp + CW - 1) / CW);
+    // the chain sweeps pick their own window width: 64 columns for long chains (every window streams the whole dense
+    // tail once), 32 for short ones (twice the workgroups on the latency-bound chain)
+    static const int chain_wide_T = getenv("SCILMM_CHAIN_WIDE_T") ? atoi(getenv("SCILMM_CHAIN_WIDE_T")) : 256;
+    auto launch_chain = [&](bool bwd) -> int {
+      const bool wide = D->chain_T >= chain_wide_T;
+      const int32_t gyc = (int32_t)((rp + (wide ? 64 : 32) - 1) / (wide ? 64 : 32));
+      const unsigned grid = (unsigned)D->chain_T * (unsigned)gyc;
+      const int32_t ep = ++D->chain_epoch;
+      HIPCHK(hipMemsetAsync(D->d_chain_err + 2, 0, sizeof(int32_t), st));
+      const int32_t* cptr = bwd ? (const int32_t*)D->d_cb_ptr : (const int32_t*)D->d_cf_ptr;
+      const ChainPair* cpairs = bwd ? (const ChainPair*)D->d_cb : (const ChainPair*)D->d_cf;
+#define SCILMM_CHAIN_LAUNCH(MF, BW, NC)                                                                                                  \
+  hipLaunchKernelGGL((k_chain<MF, BW, NC>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain, cptr, cpairs, \
+                     (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD, (const double*)D->W, D->X, rp, gyc,  \
+                     D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2)
+      if (mf) {
+        if (bwd) { if (wide) SCILMM_CHAIN_LAUNCH(true, true, 4); else SCILMM_CHAIN_LAUNCH(true, true, 2); }
+        else { if (wide) SCILMM_CHAIN_LAUNCH(true, false, 4); else SCILMM_CHAIN_LAUNCH(true, false, 2); }
+      } else {
+        if (bwd) SCILMM_CHAIN_LAUNCH(false, true, 2); else SCILMM_CHAIN_LAUNCH(false, false, 2);
+      }
+#undef SCILMM_CHAIN_LAUNCH
+      return SCILMM_OK;
+    };
     const size_t sm_fwd = sizeof(double) * (size_t)(NB * LDW + KCS * LDA);
     const int64_t tot = (int64_t)S.n * rp;
     const unsigned pb = (unsigned)((tot + 255) / 256);
@@ -2321,34 +2345,14 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
                              fac->L, (const double*)D->X, D->W, rp);
       }
       if (D->chain_T > 0) {
-        const unsigned grid = (unsigned)D->chain_T * gy;
-        const int32_t ep = ++D->chain_epoch;
-        HIPCHK(hipMemsetAsync(D->d_chain_err + 2, 0, sizeof(int32_t), st));
-        if (mf)
-          hipLaunchKernelGGL((k_chain<true, false>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
-                             (const int32_t*)D->d_cf_ptr, (const ChainPair*)D->d_cf, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
-        else
-          hipLaunchKernelGGL((k_chain<false, false>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
-                             (const int32_t*)D->d_cf_ptr, (const ChainPair*)D->d_cf, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
+        if (int e = launch_chain(false)) return e;
       }
       if (!mid_recorded) {
         HIPCHK(hipEventRecord(D->ev[4], st));
         mid_recorded = true;
       }
       if (D->chain_T > 0) {
-        const unsigned grid = (unsigned)D->chain_T * gy;
-        const int32_t ep = ++D->chain_epoch;
-        HIPCHK(hipMemsetAsync(D->d_chain_err + 2, 0, sizeof(int32_t), st));
-        if (mf)
-          hipLaunchKernelGGL((k_chain<true, true>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
-                             (const int32_t*)D->d_cb_ptr, (const ChainPair*)D->d_cb, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
-        else
-          hipLaunchKernelGGL((k_chain<false, true>), dim3(grid), dim3(512), 0, st, D->v, D->chain_T, (const int32_t*)D->d_chain,
-                             (const int32_t*)D->d_cb_ptr, (const ChainPair*)D->d_cb, (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD,
-                             (const double*)D->W, D->X, rp, (int32_t)gy, D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2);
+        if (int e = launch_chain(true)) return e;
         // descendants below the chain: all their chain targets are final now, one read-modify-write each
         if (D->chain_groups > 0) {
           if (mf)

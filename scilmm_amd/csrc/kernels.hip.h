@@ -1769,12 +1769,17 @@ __device__ unsigned long long g_chain_prof[8 * 4096];  // per front (window 0, f
 #else
 #define CPROF(slot) do {} while (0)
 #endif
-template <bool MFMA, bool BWD>
-__global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int32_t T, const int32_t* __restrict__ chain,
+// NCTW = 16-column tiles per RHS window: 2 (32 columns, two workgroups per CU: the latency-bound short chains) or 4 (64
+// columns, one workgroup per CU: long chains, where every window re-reads the whole dense tail -- 1M config: 4 -> 2 passes
+// over 127 GB per sweep).
+template <bool MFMA, bool BWD, int NCTW>
+__global__ __launch_bounds__(512, NCTW == 2 ? SCILMM_CHAIN_WAVES : 1) void k_chain(DevSym S, int32_t T, const int32_t* __restrict__ chain,
                                                const int32_t* __restrict__ pair_ptr, const ChainPair* __restrict__ pairs,
                                                const int32_t* __restrict__ colmap, const double* __restrict__ L,
                                                const double* __restrict__ invD, const double* W, double* X, int32_t rp,
                                                int32_t ncw, int32_t* flags, int32_t epoch, int32_t* err, int32_t* ticket) {
+  constexpr int CW = 16 * NCTW, LDW = NCTW == 2 ? 48 : 80, NCT = NCTW;  // (LDW == 16 mod 32, >= CW: shadows the file-wide window constants)
+  static_assert(NCTW == 2 || NCTW == 4, "k_chain: 32- or 64-column windows");
   __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // x window of the other block, then w_i: [k][c]
   __shared__ int s_ok, s_ready, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1885,7 +1890,7 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
       rowok = jrow < w;
     }
     const int kvalid = BWD ? pr.nq : wo;
-    if (e == e1 - 1) load_iv();
+    if (NCTW == 2 && e == e1 - 1) load_iv();  // (wide windows: the registers are full, the fragment is fetched after the pairs)
     if (e - e0 >= nready) {
       if (tid == 0) s_ok = chain_wait(flags + (int64_t)pr.other * ncw + c, epoch, err, e1 - 1 - e) ? 1 : 0;
       if (e == e1 - 1) CPROF(0);  // flag of the newest block observed
@@ -1957,12 +1962,13 @@ __global__ __launch_bounds__(512, SCILMM_CHAIN_WAVES) void k_chain(DevSym S, int
     __syncthreads();  // Ys is reused by the next pair
     if (e == e1 - 1) CPROF(2);  // last pair multiplied
   };
-  if (e0 == e1) load_iv();
+  if (NCTW == 2 && e0 == e1) load_iv();
   for (int32_t e = e0; e < e1 && ok; ++e) {
     double av[NK];
     load_frag(e, av);
     consume(e, av);
   }
+  if (NCTW != 2) load_iv();
   // ---- diagonal step: v = (W or X)[block i] - acc  ->  Ys,   x_i = op(invL_i) v
   if (ok) {
 #pragma unroll
