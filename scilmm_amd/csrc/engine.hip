@@ -2183,9 +2183,12 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     // the chain sweeps pick their own window width: 64 columns for long chains (every window streams the whole dense
     // tail once), 32 for short ones (twice the workgroups on the latency-bound chain)
     static const int chain_wide_T = getenv("SCILMM_CHAIN_WIDE_T") ? atoi(getenv("SCILMM_CHAIN_WIDE_T")) : 256;
+    static const int chain_full_T = getenv("SCILMM_CHAIN_FULL_T") ? atoi(getenv("SCILMM_CHAIN_FULL_T")) : 768;
     auto launch_chain = [&](bool bwd) -> int {
       const bool wide = D->chain_T >= chain_wide_T;
-      const int32_t gyc = (int32_t)((rp + (wide ? 64 : 32) - 1) / (wide ? 64 : 32));
+      const bool full = D->chain_T >= chain_full_T && rp > 64;  // every column in one 112-wide window
+      const int32_t cwc = full ? 112 : wide ? 64 : 32;
+      const int32_t gyc = (int32_t)((rp + cwc - 1) / cwc);
       const unsigned grid = (unsigned)D->chain_T * (unsigned)gyc;
       const int32_t ep = ++D->chain_epoch;
       HIPCHK(hipMemsetAsync(D->d_chain_err + 2, 0, sizeof(int32_t), st));
@@ -2196,8 +2199,8 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
                      (const int32_t*)D->d_colmap, (const double*)fac->L, (const double*)fac->invD, (const double*)D->W, D->X, rp, gyc,  \
                      D->d_chain_flags, ep, D->d_chain_err, D->d_chain_err + 2)
       if (mf) {
-        if (bwd) { if (wide) SCILMM_CHAIN_LAUNCH(true, true, 4); else SCILMM_CHAIN_LAUNCH(true, true, 2); }
-        else { if (wide) SCILMM_CHAIN_LAUNCH(true, false, 4); else SCILMM_CHAIN_LAUNCH(true, false, 2); }
+        if (bwd) { if (full) SCILMM_CHAIN_LAUNCH(true, true, 7); else if (wide) SCILMM_CHAIN_LAUNCH(true, true, 4); else SCILMM_CHAIN_LAUNCH(true, true, 2); }
+        else { if (full) SCILMM_CHAIN_LAUNCH(true, false, 7); else if (wide) SCILMM_CHAIN_LAUNCH(true, false, 4); else SCILMM_CHAIN_LAUNCH(true, false, 2); }
       } else {
         if (bwd) SCILMM_CHAIN_LAUNCH(false, true, 2); else SCILMM_CHAIN_LAUNCH(false, false, 2);
       }

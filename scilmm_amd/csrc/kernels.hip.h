@@ -1769,17 +1769,18 @@ __device__ unsigned long long g_chain_prof[8 * 4096];  // per front (window 0, f
 #else
 #define CPROF(slot) do {} while (0)
 #endif
-// NCTW = 16-column tiles per RHS window: 2 (32 columns, two workgroups per CU: the latency-bound short chains) or 4 (64
-// columns, one workgroup per CU: long chains, where every window re-reads the whole dense tail -- 1M config: 4 -> 2 passes
-// over 127 GB per sweep).
+// NCTW = 16-column tiles per RHS window: 2 (32 columns, two workgroups per CU: the latency-bound short chains), 4 (64
+// columns, one workgroup per CU) or 7 (112 columns: every fused right-hand side of an evaluation in ONE window) for long
+// chains, where every window re-reads the whole dense tail (1M config: 4 -> 1 passes over 127 GB per sweep) and the
+// fixed cost of a pair (flag, x window, two barriers) is spread over 2 - 3.5 times the MFMAs.
 template <bool MFMA, bool BWD, int NCTW>
 __global__ __launch_bounds__(512, NCTW == 2 ? SCILMM_CHAIN_WAVES : 1) void k_chain(DevSym S, int32_t T, const int32_t* __restrict__ chain,
                                                const int32_t* __restrict__ pair_ptr, const ChainPair* __restrict__ pairs,
                                                const int32_t* __restrict__ colmap, const double* __restrict__ L,
                                                const double* __restrict__ invD, const double* W, double* X, int32_t rp,
                                                int32_t ncw, int32_t* flags, int32_t epoch, int32_t* err, int32_t* ticket) {
-  constexpr int CW = 16 * NCTW, LDW = NCTW == 2 ? 48 : 80, NCT = NCTW;  // (LDW == 16 mod 32, >= CW: shadows the file-wide window constants)
-  static_assert(NCTW == 2 || NCTW == 4, "k_chain: 32- or 64-column windows");
+  constexpr int CW = 16 * NCTW, LDW = NCTW == 2 ? 48 : NCTW == 4 ? 80 : 112, NCT = NCTW;  // (LDW == 16 mod 32, >= CW: shadows the file-wide window constants)
+  static_assert(NCTW == 2 || NCTW == 4 || NCTW == 7, "k_chain: 32-, 64- or 112-column windows");
   __shared__ __attribute__((aligned(16))) double Ys[NB * LDW];  // x window of the other block, then w_i: [k][c]
   __shared__ int s_ok, s_ready, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1836,13 +1837,16 @@ __global__ __launch_bounds__(512, NCTW == 2 ? SCILMM_CHAIN_WAVES : 1) void k_cha
   };  // (lanes / k-steps outside the triangle are masked where iv is used)
   const double* Yin = BWD ? (const double*)X : W;
   double yv[NCT][4];
+  auto load_yv = [&]() {
 #pragma unroll
-  for (int cn = 0; cn < NCT; ++cn)
+    for (int cn = 0; cn < NCT; ++cn)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int jr = 16 * wv + lk + 4 * r;
-      yv[cn][r] = (jr < w && cn < ncn) ? Yin[(int64_t)(c0 + jr) * rp + c_lo + 16 * cn + li] : 0.0;
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int jr = 16 * wv + lk + 4 * r;
+        yv[cn][r] = (jr < w && cn < ncn) ? Yin[(int64_t)(c0 + jr) * rp + c_lo + 16 * cn + li] : 0.0;
+      }
+  };
+  if (NCTW == 2) load_yv();  // (wide windows: after the pairs, like the inverse fragment)
   d4 acc[NCT];
 #pragma unroll
   for (int cn = 0; cn < NCT; ++cn) acc[cn] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1902,26 +1906,29 @@ __global__ __launch_bounds__(512, NCTW == 2 ? SCILMM_CHAIN_WAVES : 1) void k_cha
       // Plain (cached) loads are safe: nothing read x of that block on this CU / XCD before its flag was seen,
       // and a 128-byte line never holds data of two producers (windows are 256-byte aligned).
       const int nx = BWD ? pr.nq : wo;
-      const int cc = tid & 63;
-      if (cc < LDW) {
-        // all rows of this thread are requested before the first one is written to LDS (the loop form waited
-        // for every load in turn: 16 exposed latencies on the critical path of the sweep)
-        double xv[NB / 8];
 #pragma unroll
-        for (int u = 0; u < NB / 8; ++u) {
-          const int k = (tid >> 6) + 8 * u;
-          xv[u] = 0.0;
-          if (k < nx && cc < rpl) {
-            int64_t xr;
-            if (!BWD) xr = co + k;
-            else xr = (pr.jp0 >= 0) ? co + pr.jp0 + k : S.sn_rows[S.sn_rowptr[s] + pr.p0 + k];
-            xv[u] = X[xr * rp + c_lo + cc];
+      for (int cbase = 0; cbase < LDW; cbase += 64) {  // (windows wider than 64 columns: two passes)
+        const int cc = cbase + (tid & 63);
+        if (cc < LDW) {
+          // all rows of this thread are requested before the first one is written to LDS (the loop form waited
+          // for every load in turn: 16 exposed latencies on the critical path of the sweep)
+          double xv[NB / 8];
+#pragma unroll
+          for (int u = 0; u < NB / 8; ++u) {
+            const int k = (tid >> 6) + 8 * u;
+            xv[u] = 0.0;
+            if (k < nx && cc < rpl) {
+              int64_t xr;
+              if (!BWD) xr = co + k;
+              else xr = (pr.jp0 >= 0) ? co + pr.jp0 + k : S.sn_rows[S.sn_rowptr[s] + pr.p0 + k];
+              xv[u] = X[xr * rp + c_lo + cc];
+            }
           }
-        }
 #pragma unroll
-        for (int u = 0; u < NB / 8; ++u) {
-          const int k = (tid >> 6) + 8 * u;
-          if (k < kn) Ys[k * LDW + cc] = xv[u];
+          for (int u = 0; u < NB / 8; ++u) {
+            const int k = (tid >> 6) + 8 * u;
+            if (k < kn) Ys[k * LDW + cc] = xv[u];
+          }
         }
       }
     }
@@ -1968,7 +1975,10 @@ __global__ __launch_bounds__(512, NCTW == 2 ? SCILMM_CHAIN_WAVES : 1) void k_cha
     load_frag(e, av);
     consume(e, av);
   }
-  if (NCTW != 2) load_iv();
+  if (NCTW != 2) {
+    load_iv();
+    load_yv();
+  }
   // ---- diagonal step: v = (W or X)[block i] - acc  ->  Ys,   x_i = op(invL_i) v
   if (ok) {
 #pragma unroll
