@@ -26,9 +26,9 @@ import bench  # noqa: E402
 SEED_FIT = 1
 
 
-def fit_hip(name, A, C, y):
+def fit_hip(name, A, C, y, aireml=False, exact_trace=False):
     P = importlib.import_module("scilmm_amd.SparseCholesky")
-    chol = P.SparseCholesky()
+    chol = P.SparseCholesky(exact_trace=exact_trace)
     log, trace = [], []
     orig = P.bolt_gradient_estimation
 
@@ -36,17 +36,20 @@ def fit_hip(name, A, C, y):
         t = time.time()
         out = orig(x, *a, **k)
         log.append(time.time() - t)
-        trace.append((np.exp(np.asarray(x)).tolist(), float(out[0]), np.asarray(out[1]).tolist()))
+        s2 = np.exp(np.asarray(x)) if k.get("take_exp", True) else np.asarray(x)  # (AI-REML evaluates at sigma2 itself)
+        trace.append((s2.tolist(), float(out[0]), np.asarray(out[1]).tolist()))
         return out
 
     P.bolt_gradient_estimation = rec
     np.random.seed(SEED_FIT)
     t0 = time.time()
-    res = P.REML(chol, [A], C, y)
+    res = P.REML(chol, [A], C, y, aireml=aireml)
     tot = time.time() - t0
     P.bolt_gradient_estimation = orig
     best = min(trace, key=lambda t: t[1])
     return {"engine": "HIP (scilmm_amd.REML, fused evaluation, device-resident n x 100 blocks)",
+            "optimiser": "AI-REML" if aireml else "L-BFGS-B (the reference's)",
+            "trace": "exact (selected inverse)" if exact_trace else "Monte-Carlo, 100 vectors (the reference's)",
             "fit_wall_s": tot, "evaluations": len(log), "first_evaluation_s": log[0],
             "median_later_evaluation_s": float(np.median(log[1:])) if len(log) > 1 else None,
             "outside_evaluations_s": tot - sum(log),
@@ -86,6 +89,8 @@ def main():
     ap.add_argument("workload", nargs="?", default="100k", choices=sorted(bench.WORKLOADS))
     ap.add_argument("--out", default=None)
     ap.add_argument("--cpu-port", action="store_true")
+    ap.add_argument("--aireml", action="store_true", help="average-information iteration instead of L-BFGS-B")
+    ap.add_argument("--exact-trace", action="store_true", help="tr(V^-1 A_k) from the selected inverse instead of the Monte-Carlo estimate")
     ap.add_argument("--compare", default=None)
     args = ap.parse_args()
     t0 = time.time()
@@ -95,7 +100,7 @@ def main():
            "seed_pedigree": 0, "seed_fit": SEED_FIT, "sim_num": 100,
            "reference": "REML(SparseCholesky(), [A], cov, y) -- /root/reference/scilmm/SparseCholesky.py:177-189"}
     print("problem: n=%d nnz=%d  (%.1f s)" % (n, A.nnz, rec["generate_s"]), flush=True)
-    rec.update(fit_cpu_port(args.workload, A, C, y) if args.cpu_port else fit_hip(args.workload, A, C, y))
+    rec.update(fit_cpu_port(args.workload, A, C, y) if args.cpu_port else fit_hip(args.workload, A, C, y, aireml=args.aireml, exact_trace=args.exact_trace))
     if args.compare:
         other = json.load(open(args.compare))
         rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
