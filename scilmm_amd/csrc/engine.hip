@@ -2182,8 +2182,9 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     const unsigned gy = (unsigned)((rp + CW - 1) / CW);
     // the chain sweeps pick their own window width: 64 columns for long chains (every window streams the whole dense
     // tail once), 32 for short ones (twice the workgroups on the latency-bound chain)
-    static const int chain_wide_T = getenv("SCILMM_CHAIN_WIDE_T") ? atoi(getenv("SCILMM_CHAIN_WIDE_T")) : 256;
-    static const int chain_full_T = getenv("SCILMM_CHAIN_FULL_T") ? atoi(getenv("SCILMM_CHAIN_FULL_T")) : 768;
+    // (read per call: the parity tests force each width on small chains)
+    const int chain_wide_T = getenv("SCILMM_CHAIN_WIDE_T") ? atoi(getenv("SCILMM_CHAIN_WIDE_T")) : 256;
+    const int chain_full_T = getenv("SCILMM_CHAIN_FULL_T") ? atoi(getenv("SCILMM_CHAIN_FULL_T")) : 768;
     auto launch_chain = [&](bool bwd) -> int {
       const bool wide = D->chain_T >= chain_wide_T;
       const bool full = D->chain_T >= chain_full_T && rp > 64;  // every column in one 112-wide window

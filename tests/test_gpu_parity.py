@@ -204,6 +204,8 @@ def test_factorization_is_bitwise_reproducible(monkeypatch):
                                  {"SCILMM_NO_CHAIN": "1"}, {"SCILMM_NO_MFMA": "1"}, {"SCILMM_CELL_LIMIT": "64"},
                                  {"SCILMM_HOST_CELLS": "1"}, {"SCILMM_CELL_LIMIT": "100000"}, {"SCILMM_PUSH_SLICE": "256"},
                                  {"SCILMM_CHAIN_WIDE": "1000", "SCILMM_CHAIN_CAP": "100000"},
+                                 {"SCILMM_CHAIN_WIDE_T": "1", "SCILMM_CHAIN_FULL_T": "100000"},  # 64-column chain windows
+                                 {"SCILMM_CHAIN_WIDE_T": "1", "SCILMM_CHAIN_FULL_T": "1"},       # 112-column chain windows
                                  {"SCILMM_DENSE": "0"}, {"SCILMM_DENSE": "1"}, {"SCILMM_DENSE": "1", "SCILMM_NO_MFMA": "1"},
                                  {"SCILMM_DENSE": "1", "SCILMM_NO_LOOKAHEAD": "1"}, {"SCILMM_OUTSIDE": "1"},
                                  {"SCILMM_OUTSIDE": "1", "SCILMM_DENSE": "1"}, {"SCILMM_OUTSIDE": "1", "SCILMM_NO_MFMA": "1"},
