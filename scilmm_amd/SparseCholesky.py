@@ -510,7 +510,8 @@ def _final_factor(cholesky_func, mats, coefficients):
         sym = cholesky_func.engine_for(mats)
         fac = cholesky_func.__dict__.setdefault('_factor_state', {}).get(id(sym))
         if fac is not None:
-            return fac.refactorize(coefficients)
+            # (the optimiser usually stops ON its last evaluation: the factor is then already the one asked for)
+            return fac if fac.holds(coefficients) else fac.refactorize(coefficients)
         fac = sym.factorize(coefficients)
         cholesky_func._factor_state.clear()
         cholesky_func._factor_state[id(sym)] = fac

@@ -38,6 +38,7 @@ class Symbolic(object):
         self._indptr = [np.ascontiguousarray(m.indptr, dtype=np.int64) for m in mats]
         self._indices = [np.ascontiguousarray(m.indices, dtype=np.int32) for m in mats]
         self._data = [np.ascontiguousarray(m.data, dtype=np.float64) for m in mats]
+        self._values_epoch = 0  # bumped whenever the resident values of a matrix change (Factor.holds)
         if perm is not None:
             ordering = "given"
             perm = np.ascontiguousarray(perm, dtype=np.int32)
@@ -84,6 +85,7 @@ class Symbolic(object):
         return hx.intdigest()
 
     def upload_values(self, skip=()):
+        self._values_epoch += 1
         for k in range(self.K):
             if k not in skip:
                 check(lib().scilmm_values_upload(self._h, k, ptr(self._data[k])), self._h)
@@ -97,6 +99,7 @@ class Symbolic(object):
         par = np.ascontiguousarray(parents, dtype=np.int32)
         if par.shape != (self.n, 2):
             raise ValueError("parents must be an (n, 2) table")
+        self._values_epoch += 1
         check(lib().scilmm_ibd_values_device(self._h, k, self.n, ptr(par)), self._h)
 
     def values_slots(self, k):
@@ -119,6 +122,7 @@ class Symbolic(object):
             if data.shape != self._data[k].shape:
                 raise ValueError("value array does not match the analysed pattern")
             self._data[k] = data
+        self._values_epoch += 1
         check(lib().scilmm_values_upload(self._h, k, ptr(data)), self._h)
 
     def __del__(self):
@@ -202,26 +206,37 @@ class Factor(object):
         bad = C.c_int32(-1)
         st = lib().scilmm_factorize(symbolic._h, ptr(s2), C.byref(h), C.byref(bad))
         self._h = h
-        self._s2 = s2.copy()
+        self._s2 = None
         check(st, symbolic._h, bad.value)
+        self._s2, self._epoch = s2.copy(), symbolic._values_epoch
+
+    def holds(self, sigma2):
+        """True when this object IS the factor of sum_k sigma2[k] A_k for the values now resident (so that a caller -- the
+        reference factorizes once more at the optimum, SparseCholesky.py:182 -- need not repeat a factorization it has)."""
+        return (self._s2 is not None and self._epoch == self.sym._values_epoch
+                and np.array_equal(self._s2, np.asarray(sigma2, dtype=np.float64)))
 
     def refactorize(self, sigma2):
         s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
         bad = C.c_int32(-1)
-        self._s2 = s2.copy()
+        self._s2 = None
         check(lib().scilmm_refactorize(self._h, ptr(s2), C.byref(bad)), self.sym._h, bad.value)
+        self._s2, self._epoch = s2.copy(), self.sym._values_epoch
         return self
 
     def refactorize_async(self, sigma2):
         """Queue the refactorization and return; ``wait()`` (or any use of the factor) completes it."""
         s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
-        self._s2 = s2.copy()
+        self._s2 = None
         check(lib().scilmm_refactorize_async(self._h, ptr(s2)), self.sym._h)
+        self._pending = (s2.copy(), self.sym._values_epoch)
         return self
 
     def wait(self):
         bad = C.c_int32(-1)
         check(lib().scilmm_factor_wait(self._h, C.byref(bad)), self.sym._h, bad.value)
+        if getattr(self, "_pending", None) is not None:
+            (self._s2, self._epoch), self._pending = self._pending, None
         return self
 
     def __del__(self):
@@ -244,6 +259,8 @@ class Factor(object):
     def __call__(self, b):
         """factor(b) = V^{-1} b for b of shape (n,) or (n, r).  On a factor with fp32 fronts (set_front_precision(32))
         the solve is refined against the exact V = sum_k s2_k A_k (fp64 SpMM on the device): each sweep gains ~7 digits."""
+        if getattr(self, "_pending", None) is not None:
+            self.wait()
         x = self._rhs(lib().scilmm_solve, b)
         if getattr(self.sym, "front_bits", 64) == 32 and getattr(self, "_s2", None) is not None:
             b = np.asarray(b, dtype=np.float64)
@@ -269,6 +286,7 @@ class Factor(object):
         """tr(V^-1 A_k) for every matrix of the analysis, exactly: the selected inverse on the supernodal factor (Takahashi
         recursion on the device, in place) followed by one pass over each A_k's pattern.  CONSUMES the factor: it must be
         refactorized before the next solve."""
+        self._s2 = None  # (the panels hold entries of the inverse from here on)
         check(lib().scilmm_selected_inverse(self._h), self.sym._h)
         out = np.empty(self.sym.K)
         check(lib().scilmm_inverse_traces(self._h, ptr(out)), self.sym._h)

@@ -108,6 +108,28 @@ def test_released_host_maps_keep_the_resident_values_usable():
         sym.set_values(0, A.data)
 
 
+def test_factor_knows_what_it_holds():
+    """Factor.holds: the drop-in skips the reference's extra factorization at the optimum (SparseCholesky.py:182) only when
+    the resident factor IS the one asked for -- same sigma2, same values, not consumed by the selected inverse."""
+    A = random_spd(200, 0.05, 3)
+    I = sp.identity(200, format="csr")
+    sym = _engine([A, I])
+    f = sym.factorize([0.5, 0.5])
+    assert f.holds([0.5, 0.5]) and not f.holds([0.5, 0.6])
+    f.refactorize([0.3, 0.8])
+    assert f.holds([0.3, 0.8]) and not f.holds([0.5, 0.5])
+    f.refactorize_async([0.2, 0.9])
+    assert not f.holds([0.2, 0.9])
+    f.wait()
+    assert f.holds([0.2, 0.9])
+    sym.set_values(0, 2.0 * A.data)
+    assert not f.holds([0.2, 0.9])
+    f.refactorize([0.2, 0.9])
+    assert f.holds([0.2, 0.9])
+    f.inverse_traces()
+    assert not f.holds([0.2, 0.9])
+
+
 def test_user_permutation_and_L_uniqueness():
     from oracle import oracle as O
     A = random_spd(90, 0.15, 13)
