@@ -1362,6 +1362,6 @@ __global__ __launch_bounds__(512, 1) void k_dense_f(DevSym S, int32_t dense_firs
 // 135 of 155 TFLOP/s; a fold every 4 k-steps, k_dense32's period: 107), so removing conversions and folds bought nothing,
 // and the shorter chunks (a barrier per 32 k) cost 15 %.  What the three fp32 forms share is the fp64 OPERAND stream: a
 // 256 x 128 tile reads 32 flop per HBM byte, i.e. 2.7 TB/s at 83 TFLOP/s in 128-byte pieces -- the fp32 forms are bound by
-// that stream, not by the matrix pipe (DESIGN.md section 4.2).
+// that stream, not by the matrix pipe (DESIGN.md section 4.1).
 
 }  // namespace scilmm
