@@ -630,13 +630,15 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
   }
   const std::vector<int64_t>& LOFF = D->loff;
   {
-    // k_dense pays from a few hundred tail panels on (300k pedigree: 450 panels, factorization 1.97 -> 1.90 s; 1M: 1330
-    // panels); on a short tail (100k: 135 panels) its one-workgroup-per-CU items balance worse than the explicit
-    // path's (66 -> 72 ms), so it is switched on by the width of the tail.  SCILMM_DENSE=1 / 0 forces it.
+    // The dense-tail path (k_dense_b + k_outside) serves every tail of 8192+ columns.  Round 2 kept the 100k config (15.7k
+    // columns, 123 panels) on the explicit path (its one-workgroup-per-CU items balanced worse: 66 -> 72 ms); with k_dense_b,
+    // k_outside and SHORT launches of ~128 items fitted to whole rounds of workgroups it is the faster one there too:
+    // 65.3 -> 58.6 ms (items 64 / 96 / 128 / 192 / 256 / 512: 60.0 / 59.2 / 58.6 / 60.6 / 60.9 / 60.4; without k_outside 66.3;
+    // without the fitting 62.7).  SCILMM_DENSE=1 / 0 forces it.
     const char* edn = tune_env("SCILMM_DENSE");
     const int32_t tail_w = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
     // (k_dense_b has no scalar form: with SCILMM_NO_MFMA=1 the tail goes through the explicit items of k_update2<false>)
-    D->dense_on = S.dense_first < S.nsuper && D->use_mfma && (edn ? edn[0] != '0' : tail_w >= 32768);
+    D->dense_on = S.dense_first < S.nsuper && D->use_mfma && (edn ? edn[0] != '0' : tail_w >= 8192);
     // a distributed tail is always updated by the implicit items (the batches have no explicit-combo form)
     if (D->world > 1 && D->dist_first < S.nsuper) D->dense_on = true;
     if (D->dense_on && !D->d_zeros) {
@@ -651,11 +653,10 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* eout = tune_env("SCILMM_OUTSIDE");
     int st = SCILMM_OK;
     D->outside_desc.assign((size_t)std::max(S.nsuper, 1), 0);
-    // (like k_dense it pays from a wide tail on: at the 100k config the serial launch between prelude and tail costs
-    // 3 ms of a 66 ms factorization, at 300k it saves 120 of 1800 ms -- SCILMM_OUTSIDE=1 / 0 forces it)
+    // (switched on with the dense-tail path, by the width of the tail -- SCILMM_OUTSIDE=1 / 0 forces it)
     const int32_t tail_w2 = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
     D->outside_on = S.dense_first < S.nsuper && !(edet && edet[0] == '1') && !sym->S->combos_built &&
-                    (eout ? eout[0] != '0' : tail_w2 >= 32768);
+                    (eout ? eout[0] != '0' : tail_w2 >= 8192);
     if (D->outside_on) {
       D->tail_level = S.sn_level[S.dense_first];
       const int32_t c0_tail = S.sn_start[S.dense_first];
@@ -1118,7 +1119,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* edi = tune_env("SCILMM_DENSE_ITEMS");
     const char* edf = getenv("SCILMM_DENSE_FILL");
     const int64_t dense_fill = edf ? atoll(edf) : 256;  // workgroups per round the dense item counts are fitted to (0: no fitting)
-    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : 1024);  // k_dense_b items per launch (target; round 3 with k_dense_b, 300k: 384 / 512 / 768 / 1024 / 2048 / 3072 = 1373 / 1369 / 1365 / 1357 / 1384 / 1407 ms, 1M: 27.0 vs 27.35 s)
+    // k_dense_b items per launch (target): long tails want launches of several rounds of workgroups (300k: 384 / 512 / 768 /
+    // 1024 / 2048 / 3072 = 1373 / 1369 / 1365 / 1357 / 1384 / 1407 ms, 1M: 1024 vs 2048 = 27.0 vs 27.35 s), the short chain of the
+    // 100k config short ones (see dense_on above)
+    const int32_t tail_w_items = S.dense_first < S.nsuper ? S.n - S.sn_start[S.dense_first] : 0;
+    const int64_t dense_items = std::max<int64_t>(64, edi ? atoll(edi) : tail_w_items < 24576 ? 128 : tail_w_items < 32768 ? 512 : 1024);
     const int64_t target_items = eti ? atoll(eti) : 1024, min_item = emn ? atoll(emn) : 24, max_item = std::max<int64_t>(min_item, emi ? atoll(emi) : 96);
     // cut [cb,ce) into segments; returns the number of items appended to `out` (slot = 0 placeholder)
     auto cut = [&](int32_t g, int64_t cb, int64_t ce, int64_t per_item, std::vector<UpdWork>& out) -> int64_t {
@@ -3196,7 +3201,7 @@ int scilmm_set_front_precision(scilmm_symbolic* sym, int32_t bits) {
   if (st != SCILMM_OK) return st;
   D->front_bits = bits;
   if (bits == 32 && !D->dense_on) {
-    sym->err = "fp32 fronts need the dense-tail path (tail narrower than 32768 columns: set SCILMM_TUNING=1 SCILMM_DENSE=1)";
+    sym->err = "fp32 fronts need the dense-tail path (tail narrower than 8192 columns: set SCILMM_TUNING=1 SCILMM_DENSE=1)";
     return SCILMM_ERR_STATE;
   }
   return SCILMM_OK;

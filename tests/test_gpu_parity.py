@@ -459,15 +459,15 @@ def test_device_dominance_matches_oracle_and_reference_golden():
 _CPU_PORT_100K = {}
 
 
-@pytest.mark.parametrize("env", [{}, {"SCILMM_TUNING": "1", "SCILMM_DENSE": "1", "SCILMM_OUTSIDE": "1"}],
-                         ids=["default-schedule", "dense+outside"])
+@pytest.mark.parametrize("env", [{}, {"SCILMM_TUNING": "1", "SCILMM_DENSE": "0", "SCILMM_OUTSIDE": "0"}],
+                         ids=["default-schedule", "explicit-items"])
 def test_100k_config_against_cpu_port(monkeypatch, env):
     """BASELINE configs[1] at FULL size (100k individuals, sf 0.005; 1.7 TFLOP per factorization), value by value
     against the BLAS-3 CPU port (oracle/supernodal_cpu.c) factoring the same V[P][:,P]: log-det and a 103-column
     solve to 1e-10, L*R to 1e-10, and one REML evaluation through the drop-in `bolt_gradient_estimation` against
     `reml_oracle.evaluate` driven by the CPU factor with the same np.random stream (nll 1e-10, gradient 1e-7).
-    Run with the default schedule of this size (explicit update items) and with the large-problem schedule the 300k /
-    1M configs use (k_dense_a + k_outside), forced here."""
+    Run with the default schedule (the dense-tail path of every tail of 8192+ columns: k_dense_b + k_outside, short launches at
+    this size) and with the explicit update items that were this size's default until round 3, forced here."""
     import importlib
     from oracle import oracle as O
     from oracle import reml_oracle as RO
