@@ -48,3 +48,8 @@ def test_bad_arguments_are_rejected():
         Symbolic([sp.identity(3, format="csr"), sp.identity(4, format="csr")], upload=False)
     with pytest.raises(ValueError):
         Symbolic([sp.identity(3, format="csr")], perm=np.arange(4), upload=False)
+    # the assembly maps may only be released once the values are in HBM (the device plan reads them)
+    from scilmm_amd._lib import ScilmmError
+    sym = Symbolic([sp.identity(3, format="csr")], upload=False)
+    with pytest.raises(ScilmmError):
+        sym.release_host_maps()
