@@ -1364,4 +1364,181 @@ __global__ __launch_bounds__(512, 1) void k_dense_f(DevSym S, int32_t dense_firs
 // 256 x 128 tile reads 32 flop per HBM byte, i.e. 2.7 TB/s at 83 TFLOP/s in 128-byte pieces -- the fp32 forms are bound by
 // that stream, not by the matrix pipe.
 
+// ------------------------------------------------------------------------------------------------
+// k_dense_s (RETIRED before it shipped: 86 TFLOP/s alone against k_dense32's 83 for + 50 % tail storage, see the note at the end):
+// the fp32-product dense-tail update reading an fp32 SHADOW of the tail panels (round 3).  k_dense32 above rounds
+// its fp64 operands while staging them and is bound by that operand stream: a 256 x 128 tile reads 32 flop per HBM byte, 2.6
+// TB/s at its 83 TFLOP/s (the instruction mix alone allows 107 - 135).  With front precision 32 the
+// engine therefore keeps a second, fp32 copy of every finished tail panel (k_shadow, one pass right after the panel's
+// k_trsm: + 50 % tail storage) and this kernel reads ONLY that copy: half the bytes per flop.  Same values as k_dense32's
+// operands (one rounding of the finished fp64 entry), the products on the fp32 matrix pipe, folded into fp64 accumulators
+// every 64 k; the subtraction from the fp64 panel, k_potrf, k_trsm and the solves stay fp64.  Structure = k_dense_b's:
+//  * A: a lane owns two ADJACENT target rows (32 wv + 2 li, + 1) and loads both with one 8-byte load per k (a quarter wave
+//    reads 128 contiguous bytes), straight into registers one 16-deep sub-chunk ahead;
+//  * B: 64 k-rows per LDS buffer by LDS-DMA, 4 bytes per lane (global_load_lds_dword: 64 lanes x 4 B = half a k-row per
+//    instruction -- the shadow's rows are only 4-byte aligned), two buffers, copy issued two chunks ahead; fragments are
+//    4-byte LDS reads prefetched one k-step ahead (row stride LDBF = 144 floats: conflict-free);
+//  * one barrier per 64 k; the fold follows the chunk's last product.
+// Same work items, slabs and epilogue contract as k_dense_b / k_dense32.
+__global__ __launch_bounds__(256) void k_shadow(const double* __restrict__ src, float* __restrict__ dst, int64_t cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
+constexpr size_t dense_s_lds = sizeof(float) * 2 * KBA * LDBF;
+
+__global__ __launch_bounds__(512, 1) void k_dense_s(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, const float* __restrict__ L32, int64_t base32,
+                                                    double* __restrict__ scratch, const float* __restrict__ zeros32) {
+  static_assert(NB == 128 && DTR == 256, "k_dense_s: 8 waves x 32 rows");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  float* Bimg = (float*)smem;  // [2][KBA][LDBF]
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  const int32_t ia = 32 * wv + 2 * li;                    // this lane's rows inside the item: ia, ia + 1
+  const int32_t ra = R0 + (ia < nrow ? ia : 0);           // (rows past the item's edge: the pair 0, 1, never stored; a pair that
+                                                          //  straddles the edge reads one entry past it -- the next column's, or the
+                                                          //  shadow's slack behind the last panel -- into a row that is never stored)
+  const int32_t bcol0 = lane < wj ? lane : 0, bcol1 = 64 + lane < wj ? 64 + lane : 0;
+  if (wk.k0 >= wk.k1) return;
+  struct Chunk { const float* Pd; int32_t md; int kc; };
+  int32_t kd = wk.k0, kk0 = 0;
+  auto next_chunk = [&]() {
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    Chunk c;
+    c.md = __builtin_amdgcn_readfirstlane(S.n - c0d);
+    c.Pd = L32 + uniform_i64(S.sn_loff[d] - base32 + (int64_t)kk0 * c.md + (c0j - c0d));
+    c.kc = __builtin_amdgcn_readfirstlane(min(KBA, wd - kk0));
+    kk0 += KBA;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    float* Bs = Bimg + b * KBA * LDBF;
+#pragma unroll
+    for (int i = 0; i < KBA / 8; ++i) {
+      const int kr = wv + 8 * i;
+      const float* row = c.Pd + (int64_t)kr * c.md;
+      const bool on = kr < c.kc;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + bcol0 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + bcol1 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF + 64), 4, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int s, f2 (&a)[4]) {
+    const int klast = (c.kc - 1) & ~3;
+    const uint32_t v = (uint32_t)(lk * c.md + ra) * 4u;  // byte offset of this lane's row pair in k-column lk of a 4-deep block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* sp = c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md;  // wave-uniform
+      a[q] = *(const f2*)((const char*)sp + v);
+    }
+  };
+  d4 acc[NJB][2];
+  f4 c32[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) {
+    acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0};
+    c32[a][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  f2 rA[2][4];
+  float bf[2][NJB];
+  auto ldB = [&](const float* Bc, int k4, float (&b)[NJB]) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDBF + 16 * jb + li];
+  };
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  bool more = kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  ldB(Bimg, 0, bf[0]);
+  while (true) {
+    const float* Bc = Bimg + buf * KBA * LDBF;
+    const float* Bn = Bimg + (buf ^ 1) * KBA * LDBF;
+    bool more2 = false;
+    Chunk nn = nxt;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+        if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
+      }
+      if (t < 15) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        // chunk boundary: every wave has READ its last fragments of Bc (they are in registers) and the copy of the next
+        // chunk has landed -- after this barrier Bn may be read and Bc overwritten
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.k1;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+      const f2 a = rA[s & 1][q];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        c32[jb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], a[0], c32[jb][0], 0, 0, 0);
+        c32[jb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], a[1], c32[jb][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // fold the chunk's fp32 sums (64 products each) into the fp64 accumulators
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][ib][r] += (double)c32[jb][ib][r];
+        c32[jb][ib] = (f4){0.f, 0.f, 0.f, 0.f};
+      }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ia + ib, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+        const double v = acc[jb][ib][r];
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+        }
+      }
+}
+
+// Why k_dense_s is here: it tests the explanation given for k_dense_f above.  With operands that are ALREADY fp32 in HBM (half
+// the bytes per flop, no conversions at all) it reaches 86.3 TFLOP/s on the 1M-shaped launch against 83.2 (k_dense32) and 84.5
+// (k_dense_b's streams with fp32 products); with the A fragments fetched two sub-chunks ahead and a partial vmcnt wait at the
+// chunk barrier: 78 (more spills).  So neither the operand bytes nor the conversions nor the load latency explain the 0.55 of
+// the fp32 pipe all four forms share; what does is not found (the register-only / LDS-fed probe sustains 135 - 141 with the
+// same 16 MFMAs, fragment reads and fold per k-step).  Not worth + 50 % tail storage: the engine keeps k_dense32.
+
 }  // namespace scilmm
