@@ -19,7 +19,7 @@ constexpr int KR = 64, LDBF = 144;
 template <bool GA, bool DMA, int FEAT>
 __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __restrict__ Ag, const float* __restrict__ Bg, int md, int iters,
                                                const int* __restrict__ desc, const float* __restrict__ zeros) {
-  constexpr bool PF = FEAT & 1, SEL = FEAT & 2, DESC = FEAT & 4;
+  constexpr bool PF = FEAT & 1, SEL = FEAT & 2, DESC = FEAT & 4, DESYNC = FEAT & 8;
   extern __shared__ float sm[];
   float* Bf = sm;                    // [2][KR][LDBF]
   float* Af = sm + 2 * KR * LDBF;    // [KR][272]   (A fragments when they do not come from global memory)
@@ -63,11 +63,12 @@ __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __res
       __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + 64 + lane : zeros + lane), (lds_vptr)(Bs + kr * LDBF + 64), 4, 0, 0);
     }
   };
-  long kpos = 0;
-  if (GA) load_A(0, 0, rA[0]);
+  const long kwrap = 64L * iters;
+  long kpos = DESYNC ? 64L * ((blockIdx.x * 37) % iters) : 0;
+  if (GA) load_A(kpos, 0, rA[0]);
   if (DMA) {
-    issue_B(0, 0);
-    issue_B(64, 1);
+    issue_B(kpos, 0);
+    issue_B(kpos + 64, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __res
         c[jb][ib] = (f4){0, 0, 0, 0};
       }
     kpos += 64;
+    if (DESYNC && kpos >= kwrap) kpos -= kwrap;
     buf ^= 1;
   }
   double s = 0;
@@ -187,5 +189,7 @@ int main() {
   run<true, true, 2>(d, A, B, md, iters, desc, zeros, "both + depth tests (zero page select, clamp)");
   run<true, true, 3>(d, A, B, md, iters, desc, zeros, "both + prefetch + depth tests");
   run<true, true, 7>(d, A, B, md, iters, desc, zeros, "both + prefetch + depth tests + descriptors");
+  run<true, true, 8>(d, A, B, md, iters, desc, zeros, "both, every workgroup at its own k position");
+  run<true, true, 11>(d, A, B, md, iters, desc, zeros, "both + prefetch + depth tests, own k positions");
   return 0;
 }
