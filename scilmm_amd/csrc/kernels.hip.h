@@ -533,21 +533,40 @@ __global__ __launch_bounds__(512, 1) void k_dense_b(DevSym S, int32_t dense_firs
   const double* zsrc = zeros + 2 * lane;
   struct Chunk { const double* Pd; int32_t md; int kc; uint32_t v0, v1; };
   int32_t kd = wk.k0, kk0 = 0;
+  // (the descendant's entries of the symbolic arrays are read once per descendant, not once per chunk: a descriptor built at the
+  //  chunk boundary from fresh loads stalls every wave for their latency right before the last k-step's MFMAs)
+  int32_t d_wd = 0, d_md = 0;
+  const double* d_P0 = nullptr;  // column 0 of the current descendant's panel, at the target's first column's row
   auto next_chunk = [&]() {
-    const int32_t d = dense_first + kd;
-    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
+    if (kk0 == 0) {
+      const int32_t d = dense_first + kd;
+      const int32_t c0d = S.sn_start[d];
+      d_wd = __builtin_amdgcn_readfirstlane(S.sn_start[d + 1] - c0d);
+      d_md = __builtin_amdgcn_readfirstlane(S.n - c0d);
+      d_P0 = L + uniform_i64(S.sn_loff[d] + (c0j - c0d));
+    }
     Chunk c;
-    c.md = __builtin_amdgcn_readfirstlane(S.n - c0d);
-    c.Pd = L + uniform_i64(S.sn_loff[d] + (int64_t)kk0 * c.md + (c0j - c0d));
-    c.kc = __builtin_amdgcn_readfirstlane(min(KBA, wd - kk0));
+    c.md = d_md;
+    c.Pd = d_P0 + (int64_t)kk0 * d_md;
+    c.kc = min(KBA, d_wd - kk0);
     c.v0 = (uint32_t)(lk * c.md + ra0) * 8u;  // byte offsets of this lane's rows in the k-column lk of a 4-deep block
     c.v1 = (uint32_t)(lk * c.md + ra1) * 8u;
     kk0 += KBA;
-    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    if (kk0 >= d_wd) { kk0 = 0; ++kd; }
     return c;
   };
   auto issue_B = [&](const Chunk& c, int b) {
     double* Bs = smem + b * KBA * LDB;
+    if (c.kc == KBA) {
+      // full chunk (all but a descendant's last one): no depth test per k-row -- the generic form below costs a scalar compare,
+      // a branch and a 64-bit address rebuild per copy instruction, between the chunk barrier and the last k-step's MFMAs
+      const double* p = c.Pd + (int64_t)wv * c.md + b_off;
+      const int64_t step = 8 * (int64_t)c.md;
+#pragma unroll
+      for (int i = 0; i < KBA / 8; ++i)
+        __builtin_amdgcn_global_load_lds((gl_vptr)(p + i * step), (lds_vptr)(Bs + (wv + 8 * i) * LDB), 16, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KBA / 8; ++i) {
       const int kr = wv + 8 * i;
