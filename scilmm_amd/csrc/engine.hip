@@ -1657,6 +1657,7 @@ int set_attrs(scilmm_symbolic* sym, Dev* D) {
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_fwd<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense32, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+  HIPCHK(hipFuncSetAttribute((const void*)k_dense_h, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_dense_b, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   HIPCHK(hipFuncSetAttribute((const void*)k_update2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -1702,6 +1703,8 @@ struct scilmm_factor {
   bool external = false;      // L / invD / logd belong to the caller (scilmm_factor_create_external)
   bool pending = false;       // a factorization has been queued (scilmm_refactorize_async) and not yet waited for
   bool inverted = false;      // L has been replaced by the selected inverse (scilmm_selected_inverse): no solves until refactorized
+  float* L32 = nullptr;       // front precision 32: fp32 shadow of the dense-tail panels (k_shadow / k_dense_h), else null
+  int64_t base32 = 0;         // index in L of the shadow's first entry (= sn_loff[dense_first])
   int32_t* h_status = nullptr;  // pinned host copy of *status, filled by the queued copy
 };
 
@@ -1741,6 +1744,28 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   const size_t sm_potrf = sizeof(double) * (size_t)((NB / 2) * (NB + 1) + NJB * 16 * 17 + 32);
   hipStream_t st = D->stream;
   int64_t launches = 0;
+  {
+    // front precision 32 on one GPU: the dense-tail kernel reads an fp32 shadow of the finished tail panels (k_dense_h).  It
+    // is allocated with the first such factorization and kept (zeroed once: the kernel may read a few entries past a panel,
+    // into the next panel's or the slack's, which must be finite); a distributed tail keeps k_dense32 (fp64 operands: the
+    // ring slots have no shadow), and so does a device without room for it.  SCILMM_TUNING=1 SCILMM_SHADOW=0: k_dense32.
+    const char* esh = tune_env("SCILMM_SHADOW");
+    const bool want = D->front_bits == 32 && D->dense_on && !dist && !(esh && esh[0] == '0');
+    if (want && !fac->L32) {
+      fac->base32 = S.sn_loff[S.dense_first];
+      const size_t cnt32 = (size_t)(S.sn_loff[S.nsuper] - fac->base32) + 16384;
+      if (hipMalloc((void**)&fac->L32, sizeof(float) * cnt32) != hipSuccess) {
+        (void)hipGetLastError();
+        fac->L32 = nullptr;
+      } else {
+        HIPCHK(hipMemsetAsync(fac->L32, 0, sizeof(float) * cnt32, st));
+      }
+    } else if (!want && fac->L32) {
+      HIPCHK(hipStreamSynchronize(st));
+      (void)hipFree(fac->L32);
+      fac->L32 = nullptr;
+    }
+  }
   HIPCHK(hipEventRecord(D->ev[0], st));
   HIPCHK(hipMemsetAsync(fac->L, 0, sizeof(double) * (size_t)std::max<int64_t>(D->nL_local, 1), st));
   int32_t big = 0x7fffffff;
@@ -1801,9 +1826,13 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     }
   };
   auto launch_dense = [&](hipStream_t stream, const DenseWork* dw, int64_t cnt, double* scratch_half) {
-    for (int64_t o = 0; o < cnt; o += max_groups(512)) {
-      const unsigned c = (unsigned)std::min<int64_t>(cnt - o, max_groups(512));
-      if (D->front_bits == 32)
+    for (int64_t o = 0; o < cnt; o += max_groups(1024)) {
+      const unsigned c = (unsigned)std::min<int64_t>(cnt - o, max_groups(1024));  // (k_dense_h launches 2 c workgroups of 512)
+      if (D->front_bits == 32 && fac->L32)
+        // (two workgroups per work item: one per 128-row tile)
+        hipLaunchKernelGGL(k_dense_h, dim3(2 * c), dim3(512), dense_h_lds, stream, D->v, S.dense_first, dw + o, fac->L, (const float*)fac->L32,
+                           fac->base32, scratch_half, (const float*)D->d_zeros);
+      else if (D->front_bits == 32)
         hipLaunchKernelGGL(k_dense32, dim3(c), dim3(512), sizeof(float) * (size_t)(2 * KC * LDA2F + 2 * KC * LDBF), stream, D->v,
                            S.dense_first, dw + o, fac->L, scratch_half);
       else
@@ -1922,6 +1951,18 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         hipLaunchKernelGGL(k_trsm<false>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD,
                            (const int32_t*)D->d_tile_pslot, (const int32_t*)D->d_tile_pnseg, (const double*)sh);
       launches++;
+    }
+    if (fac->L32) {
+      // front precision 32: the level's finished tail panel -> its fp32 shadow, before the level's event (the look-ahead
+      // launches of later targets read the shadow only)
+      for (int32_t q = f0; q < f1; ++q) {
+        const int32_t fr = S.level_fronts[q];
+        if (fr < S.dense_first) continue;
+        const int64_t cnt = S.sn_loff[fr + 1] - S.sn_loff[fr];
+        hipLaunchKernelGGL(k_shadow, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 8192)), dim3(256), 0, st,
+                           (const double*)(fac->L + S.sn_loff[fr]), fac->L32 + (S.sn_loff[fr] - fac->base32), cnt);
+        launches++;
+      }
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 4], st));
     if (tf < 0) {
@@ -2686,6 +2727,7 @@ void scilmm_factor_free(scilmm_factor* fac) {
     if (fac->logd) (void)hipFree(fac->logd);
   }
   if (fac->status) (void)hipFree(fac->status);
+  if (fac->L32) (void)hipFree(fac->L32);
   delete fac;
 }
 

@@ -803,6 +803,217 @@ __global__ __launch_bounds__(512, 1) void k_dense32(DevSym S, int32_t dense_firs
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_dense_h: the fp32-product dense-tail update, round 3's final form.  The four earlier forms (k_dense32 above; three rewrites in
+// csrc/tools/retired_kernels.hip.h) all run at 83 - 88 TFLOP/s, 0.55 of the fp32 matrix pipe, whatever their operand format --
+// while a synthetic loop with the same operand feeds sustains 114 - 124 on a launch of the real shape (csrc/tools/mfma_f32_feed,
+// mfma_f32_wave64; profiles/r3_mfma_f32_feed.txt).  What the real kernels have and the synthetic loop has not is REGISTER
+// PRESSURE: a wave that owns 32 rows x 128 columns needs 128 registers of fp64 sums + 64 of fp32 sums + fragments + addressing,
+// more than the 256 a wave has at two waves per SIMD; the spilled accumulators come back from scratch -- through the memory
+// pipeline the 1 - 2 TB/s operand stream is using -- exactly where a chunk's fold needs them (k_dense_s without its fp64
+// accumulators: 134 registers, 118 TFLOP/s instead of 86; with the whole register file for one wave per SIMD and 64 x 128 per
+// wave the compiler still spills: 69).  Here a wave owns 32 rows x 64 COLUMNS -- the eight waves tile a 128-row x 128-column
+// workgroup tile 4 x 2 -- so the sums take 64 + 32 registers and nothing spills.  Two workgroups serve one work item (its two
+// 128-row tiles); HBM bytes per flop are unchanged (they depend on the columns per workgroup), the two column halves of a row
+// group load the same A rows (the second load hits L1 / L2).
+// Operands come from an fp32 SHADOW of the finished tail panels (k_shadow right after a panel's k_trsm; same column-major
+// layout, + 50 % tail storage): half the bytes of the fp64 panels per flop, no conversion in the loop.  Values = k_dense32's
+// operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 64 k; the
+// subtraction from the fp64 panel, k_potrf, k_trsm and the solves stay fp64.  Loop = k_dense_b's: A fragments (a lane's two
+// adjacent rows, one 8-byte load per k) straight into registers one 16-deep sub-chunk ahead, B image (64 k-rows x 128 columns)
+// by LDS-DMA 4 bytes per lane, fragments prefetched one k-step ahead, one barrier per 64 k; the item's descendants' symbolic
+// entries sit in an LDS table.  Same work items, slabs and epilogue contract as k_dense_b / k_dense32.
+__global__ __launch_bounds__(256) void k_shadow(const double* __restrict__ src, float* __restrict__ dst, int64_t cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
+#ifndef SCILMM_DENSE_H_FOLD
+#define SCILMM_DENSE_H_FOLD 2   // chunks of 64 k between two folds of the fp32 sums into the fp64 accumulators (a power of two)
+#endif
+#ifndef SCILMM_DENSE_H_WGS
+#define SCILMM_DENSE_H_WGS 4    // waves per SIMD the register budget is cut for (4 = two workgroups per CU: 128 registers per wave)
+#endif
+constexpr int DH_MAXD = 256;  // descendants per item held in the LDS table (the plan's items have <= 64)
+constexpr size_t dense_h_lds = sizeof(float) * 2 * KBA * LDBF + sizeof(int32_t) * (DH_MAXD + 2) + sizeof(int64_t) * DH_MAXD;
+
+__global__ __launch_bounds__(512, SCILMM_DENSE_H_WGS) void k_dense_h(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, const float* __restrict__ L32, int64_t base32,
+                                                    double* __restrict__ scratch, const float* __restrict__ zeros32) {
+  static_assert(NB == 128 && TM == 128, "k_dense_h: 4 x 2 waves of 32 rows x 64 columns");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  float* Bimg = (float*)smem;                            // [2][KBA][LDBF]
+  int32_t* t_c0 = (int32_t*)(Bimg + 2 * KBA * LDBF);     // [DH_MAXD + 2]  first columns of the item's descendants
+  int64_t* t_lo = (int64_t*)(t_c0 + DH_MAXD + 2);        // [DH_MAXD]      their panel offsets
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int NJH = NJB / 2;  // 16-column blocks per wave
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wv >> 1, ch = wv & 1;  // row group (32 rows) / column half (64 columns) of this wave
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x >> 1];
+  const int th = blockIdx.x & 1;        // which of the item's two 128-row tiles
+  if (th >= wk.ntiles || wk.k0 >= wk.k1) return;
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = (wk.ti0 + th) * TM;
+  const int32_t nrow = min(TM, mj - R0);
+  const int32_t slot = th ? wk.slot1 : wk.slot0;
+  const int32_t ndesc = min(wk.k1 - wk.k0, DH_MAXD);
+  for (int i = tid; i <= ndesc; i += 512) t_c0[i] = S.sn_start[dense_first + wk.k0 + i];
+  for (int i = tid; i < ndesc; i += 512) t_lo[i] = S.sn_loff[dense_first + wk.k0 + i];
+  const int32_t ia = 32 * rg + 2 * li;                    // this lane's rows inside the tile: ia, ia + 1
+  const int32_t ra = R0 + (ia < nrow ? ia : 0);           // (rows past the tile's edge: the pair 0, 1, never stored; a pair that
+                                                          //  straddles the edge reads one entry past it into a row that is never stored)
+  const int32_t bcol0 = lane < wj ? lane : 0, bcol1 = 64 + lane < wj ? 64 + lane : 0;
+  __syncthreads();
+  struct Chunk { const float* Pd; int32_t md; int kc; };
+  int32_t kd = wk.k0, kk0 = 0;
+  auto next_chunk = [&]() {
+    const int32_t e = kd - wk.k0, d = dense_first + kd;
+    const bool tab = e < DH_MAXD;
+    const int32_t c0d = __builtin_amdgcn_readfirstlane(tab ? t_c0[e] : S.sn_start[d]);
+    const int32_t wd = __builtin_amdgcn_readfirstlane(tab ? t_c0[e + 1] : S.sn_start[d + 1]) - c0d;
+    Chunk c;
+    c.md = S.n - c0d;
+    c.Pd = L32 + (uniform_i64(tab ? t_lo[e] : S.sn_loff[d]) - base32 + (int64_t)kk0 * c.md + (c0j - c0d));
+    c.kc = min(KBA, wd - kk0);
+    kk0 += KBA;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    float* Bs = Bimg + b * KBA * LDBF;
+#pragma unroll
+    for (int i = 0; i < KBA / 8; ++i) {
+      const int kr = wv + 8 * i;
+      const float* row = c.Pd + (int64_t)kr * c.md;
+      const bool on = kr < c.kc;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + bcol0 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + bcol1 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF + 64), 4, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int s, f2 (&a)[4]) {
+    const int klast = (c.kc - 1) & ~3;
+    const uint32_t v = (uint32_t)(lk * c.md + ra) * 4u;  // byte offset of this lane's row pair in k-column lk of a 4-deep block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* sp = c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md;  // wave-uniform
+      a[q] = *(const f2*)((const char*)sp + v);
+    }
+  };
+  d4 acc[NJH][2];
+  f4 c32[NJH][2];
+#pragma unroll
+  for (int a = 0; a < NJH; ++a) {
+    acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0};
+    c32[a][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  f2 rA[2][4];
+  float bf[2][NJH];
+  int cidx = 0;  // chunks multiplied so far
+  auto ldB = [&](const float* Bc, int k4, float (&b)[NJH]) {
+#pragma unroll
+    for (int jb = 0; jb < NJH; ++jb) b[jb] = Bc[(k4 + lk) * LDBF + 64 * ch + 16 * jb + li];
+  };
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  bool more = kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  ldB(Bimg, 0, bf[0]);
+  while (true) {
+    const float* Bc = Bimg + buf * KBA * LDBF;
+    const float* Bn = Bimg + (buf ^ 1) * KBA * LDBF;
+    bool more2 = false;
+    Chunk nn = nxt;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+        if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
+      }
+      if (t < 15) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        // chunk boundary: every wave has READ its last fragments of Bc (they are in registers) and the copy of the next
+        // chunk has landed -- after this barrier Bn may be read and Bc overwritten
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.k1;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+      const f2 a = rA[s & 1][q];
+#pragma unroll
+      for (int jb = 0; jb < NJH; ++jb) {
+        c32[jb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], a[0], c32[jb][0], 0, 0, 0);
+        c32[jb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], a[1], c32[jb][1], 0, 0, 0);
+      }
+#ifndef SCILMM_DENSE_H_NOFOLD  // (fold experiment of csrc/tools/dense_bench2: fp32 sums over the whole item, WRONG error model)
+      if (t == 15 && (cidx & (SCILMM_DENSE_H_FOLD - 1)) == SCILMM_DENSE_H_FOLD - 1) {
+        // fold the fp32 sums into the fp64 accumulators every SCILMM_DENSE_H_FOLD chunks of 64 k.  The fold is ~100 double-
+        // precision vector instructions per wave, and on gfx950 the fp32 matrix instructions run at the fp32 VECTOR rate: the
+        // kernel alone runs at 117 TFLOP/s without any fold, 95.7 folding every chunk -- whether the two waves of a SIMD fold
+        // at the same k-step or eight k-steps apart (92.6): the fold's time ADDS to the products'.
+#pragma unroll
+        for (int jb = 0; jb < NJH; ++jb)
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[jb][ib][r] += (double)c32[jb][ib][r];
+            c32[jb][ib] = (f4){0.f, 0.f, 0.f, 0.f};
+          }
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    buf ^= 1;
+    ++cidx;
+  }
+#ifndef SCILMM_DENSE_H_NOFOLD
+#pragma unroll
+  for (int jb = 0; jb < NJH; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[jb][ib][r] += (double)c32[jb][ib][r];
+#endif
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJH; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ia + ib, jc = 64 * ch + 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+#ifdef SCILMM_DENSE_H_NOFOLD
+        const double v = (double)c32[jb][ib][r];
+#else
+        const double v = acc[jb][ib][r];
+#endif
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + i] = v;
+        }
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_outside: the contribution of a PRELUDE front to the dense tail, computed in the descendant's own coordinates.
 // The rows of descendant d that lie in the tail (rows t0 .. m_d of its panel) are contiguous in the panel, so the
 // products  U = L_d[t0:, :] * L_d[t0:, :]^T  are plain dense 128 x 128 x w_d block products with no padding at all

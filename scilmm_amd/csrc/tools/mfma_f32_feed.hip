@@ -19,7 +19,7 @@ constexpr int KR = 64, LDBF = 144;
 template <bool GA, bool DMA, int FEAT>
 __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __restrict__ Ag, const float* __restrict__ Bg, int md, int iters,
                                                const int* __restrict__ desc, const float* __restrict__ zeros) {
-  constexpr bool PF = FEAT & 1, SEL = FEAT & 2, DESC = FEAT & 4, DESYNC = FEAT & 8;
+  constexpr bool PF = FEAT & 1, SEL = FEAT & 2, DESC = FEAT & 4, DESYNC = FEAT & 8, ITEMS = FEAT & 16;
   extern __shared__ float sm[];
   float* Bf = sm;                    // [2][KR][LDBF]
   float* Af = sm + 2 * KR * LDBF;    // [KR][272]   (A fragments when they do not come from global memory)
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __res
 #pragma unroll
     for (int b = 0; b < 2; ++b) { c[a][b] = (f4){0, 0, 0, 0}; acc[a][b] = (d4){0, 0, 0, 0}; }
   // this workgroup's A region: rows R0 .. R0 + 255 of a column-major [md x K] float matrix; k advances with the chunks
-  const float* Abase = Ag + (size_t)blockIdx.x * 256 + 32 * wv + 2 * li;
+  const int npair = 347;
+  const float* Abase = Ag + (size_t)(ITEMS ? blockIdx.x % npair : blockIdx.x) * 256 + 32 * wv + 2 * li;
   f2 rA[2][4];
   int kc_cur = 64;  // SEL: chunk depth (always 64 here, but the kernel does not know)
   auto load_A = [&](long k0, int sub, f2 (&a)[4]) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __res
     }
   };
   const long kwrap = 64L * iters;
-  long kpos = DESYNC ? 64L * ((blockIdx.x * 37) % iters) : 0;
+  long kpos = ITEMS ? 64L * iters * (blockIdx.x / npair) : DESYNC ? 64L * ((blockIdx.x * 37) % iters) : 0;
   if (GA) load_A(kpos, 0, rA[0]);
   if (DMA) {
     issue_B(kpos, 0);
@@ -142,11 +143,10 @@ __global__ __launch_bounds__(512, 1) void k_feed(double* out, const float* __res
 }
 
 template <bool GA, bool DMA, int FEAT>
-void run(double* d, const float* A, const float* B, int md, int iters, const int* desc, const float* zeros, const char* what) {
+void run(double* d, const float* A, const float* B, int md, int iters, const int* desc, const float* zeros, const char* what, int grid = 256) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int grid = 256;
   const size_t lds = sizeof(float) * (2 * KR * LDBF + KR * 272);
   (void)hipFuncSetAttribute((const void*)k_feed<GA, DMA, FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   for (int rep = 0; rep < 3; ++rep) {
@@ -166,7 +166,7 @@ int main() {
   const size_t K = 64 * (size_t)(iters + 4);
   double* d;
   float *A, *B;
-  (void)hipMalloc(&d, sizeof(double) * 512 * 256);
+  (void)hipMalloc(&d, sizeof(double) * 512 * 8192);
   (void)hipMalloc(&A, sizeof(float) * (size_t)md * K);  // 6.9 GB: every workgroup streams its own rows, nothing is re-read
   (void)hipMemset(A, 0, sizeof(float) * (size_t)md * K);
   B = A;                                                 // the B rows: columns 0..127 of the same matrix (shared by all workgroups)
@@ -191,5 +191,16 @@ int main() {
   run<true, true, 7>(d, A, B, md, iters, desc, zeros, "both + prefetch + depth tests + descriptors");
   run<true, true, 8>(d, A, B, md, iters, desc, zeros, "both, every workgroup at its own k position");
   run<true, true, 11>(d, A, B, md, iters, desc, zeros, "both + prefetch + depth tests, own k positions");
+  {
+    // a launch shaped like the real one: 15 K segments x 347 row pairs = 5205 workgroups of 96 chunks, segment-major
+    const int md2 = 347 * 256 + 64, it2 = 96;
+    float* A2;
+    (void)hipFree(A);
+    (void)hipMalloc(&A2, sizeof(float) * (size_t)md2 * 64 * (size_t)(15 * it2 + 4));
+    (void)hipMemset(A2, 0, sizeof(float) * (size_t)md2 * 64 * (size_t)(15 * it2 + 4));
+    run<true, true, 16 + 3>(d, A2, A2, md2, it2, desc, zeros, "5205 items (15 segments x 347 row pairs), 96 chunks each", 5205);
+    run<true, true, 16 + 3>(d, A2, A2, md2, it2, desc, zeros, "... 256 of them (one round)", 256);
+    run<true, true, 16 + 3>(d, A2, A2, md2, it2, desc, zeros, "... 2560 of them (ten full rounds)", 2560);
+  }
   return 0;
 }

@@ -1380,9 +1380,6 @@ __global__ __launch_bounds__(512, 1) void k_dense_f(DevSym S, int32_t dense_firs
 //    4-byte LDS reads prefetched one k-step ahead (row stride LDBF = 144 floats: conflict-free);
 //  * one barrier per 64 k; the fold follows the chunk's last product.
 // Same work items, slabs and epilogue contract as k_dense_b / k_dense32.
-__global__ __launch_bounds__(256) void k_shadow(const double* __restrict__ src, float* __restrict__ dst, int64_t cnt) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
-}
 
 constexpr size_t dense_s_lds = sizeof(float) * 2 * KBA * LDBF;
 
@@ -1500,6 +1497,207 @@ __global__ __launch_bounds__(512, 1) void k_dense_s(DevSym S, int32_t dense_firs
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifndef SCILMM_DENSE_S_NOFOLD
+    // fold the chunk's fp32 sums (64 products each) into the fp64 accumulators
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][ib][r] += (double)c32[jb][ib][r];
+        c32[jb][ib] = (f4){0.f, 0.f, 0.f, 0.f};
+      }
+#endif
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ia + ib, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+#ifdef SCILMM_DENSE_S_NOFOLD
+        const double v = (double)c32[jb][ib][r];  // (register-pressure experiment: fp32 sums over the whole item)
+#else
+        const double v = acc[jb][ib][r];
+#endif
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+        }
+      }
+}
+
+// Why k_dense_s is here: it tests the explanation given for k_dense_f above.  With operands that are ALREADY fp32 in HBM (half
+// the bytes per flop, no conversions at all) it reaches 86.3 TFLOP/s on the 1M-shaped launch against 83.2 (k_dense32) and 84.5
+// (k_dense_b's streams with fp32 products); with the A fragments fetched two sub-chunks ahead and a partial vmcnt wait at the
+// chunk barrier: 78 (more spills).  So neither the operand bytes nor the conversions nor the load latency explain the 0.55 of
+// the fp32 pipe all four forms share; what does is not found (the register-only / LDS-fed probe sustains 135 - 141 with the
+// same 16 MFMAs, fragment reads and fold per k-step).  Not worth + 50 % tail storage: the engine keeps k_dense32.
+
+// ------------------------------------------------------------------------------------------------
+// k_dense_t (RETIRED before it shipped: 87 - 88 TFLOP/s alone, as the other two-waves-per-SIMD forms; the note at the end):
+// the fp32-product dense-tail update on a TILE-MAJOR fp32 shadow of the tail panels (round 3).  The fp32-product
+// kernels are bound by the DRAM efficiency of their A stream (csrc/tools/mfma_f32_feed): out of a
+// column-major panel a workgroup reads one 1 KB piece of 256 rows per k-column, strided by the leading dimension, and the same
+// loop runs at twice the rate on long runs.  With front precision 32 the engine therefore keeps an fp32 copy of every finished
+// tail panel in 128-ROW BLOCKS (k_shadow_t, one pass right after the panel's k_trsm): block b of panel d holds the panel's rows
+// with tail index g = row - c0_tail in [128 b, 128 b + 128) as [k][128 rows], consecutive k adjacent -- a wave's 32 rows of one
+// descendant are ONE contiguous run (128 B per k, 16 KB per 128-wide descendant block), whatever the other workgroups do.
+//   shadow(d)[((g >> 7) - (c0_d - c0_tail >> 7)) * w_d + k) * 128 + (g & 127)] = (float) L_d[row g, column k]
+// Operand values, products, folds and the epilogue are k_dense32's (one rounding of the finished fp64 entry; fp32 MFMA, fp64 sums
+// every 64 k; fp64 subtraction); loop structure = k_dense_b's (A straight into registers one sub-chunk ahead, B image by LDS-DMA
+// 4 bytes per lane, one barrier per 64 k).
+__global__ __launch_bounds__(256) void k_shadow_t(const double* __restrict__ P, float* __restrict__ dst, int32_t g0, int32_t md, int32_t w) {
+  // one panel: element (r, k) -> block-major; threads run along r (coalesced reads and writes)
+  const int64_t cnt = (int64_t)md * w;
+  const int32_t b0 = g0 >> 7;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) {
+    const int32_t k = (int32_t)(i / md), r = (int32_t)(i - (int64_t)k * md);
+    const int32_t g = g0 + r;
+    dst[((int64_t)((g >> 7) - b0) * w + k) * 128 + (g & 127)] = (float)P[i];
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void k_dense_t(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, const float* __restrict__ S32,
+                                                    const int64_t* __restrict__ soff, double* __restrict__ scratch,
+                                                    const float* __restrict__ zeros32) {
+  static_assert(NB == 128 && DTR == 256, "k_dense_t: 8 waves x 32 rows");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  float* Bimg = (float*)smem;  // [2][KBA][LDBF]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0t = S.sn_start[dense_first];
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  const int32_t ia = 32 * wv + li, ib_ = ia + 16;  // this lane's rows inside the item (k_dense_b's assignment)
+  // tail indices g of the lane's two A rows and of its two B columns (rows c0j + col of the descendant panels)
+  const int32_t gA0 = c0j - c0t + R0 + (ia < nrow ? ia : 0), gA1 = c0j - c0t + R0 + (ib_ < nrow ? ib_ : 0);
+  const int32_t gB0 = c0j - c0t + (lane < wj ? lane : 0), gB1 = c0j - c0t + (64 + lane < wj ? 64 + lane : 0);
+  if (wk.k0 >= wk.k1) return;
+  // The item's descendants' entries of the symbolic arrays go to LDS ONCE, up front: a chunk descriptor built from global
+  // loads at the chunk boundary stalls every wave of the workgroup for a memory latency right before the last k-step's MFMAs
+  // (csrc/tools/mfma_f32_feed: that alone takes the loop from 125 to 73 TFLOP/s)
+  constexpr int DMAXD = 256;  // descendants per item the LDS table holds (the plan's items have <= 64)
+  int32_t* t_c0 = (int32_t*)(Bimg + 2 * KBA * LDBF);   // [DMAXD + 1]
+  int64_t* t_so = (int64_t*)(t_c0 + DMAXD + 2);         // [DMAXD]
+  const int32_t ndesc = min(wk.k1 - wk.k0, DMAXD);
+  for (int i = tid; i <= ndesc; i += 512) t_c0[i] = S.sn_start[dense_first + wk.k0 + i];
+  for (int i = tid; i < ndesc; i += 512) t_so[i] = soff[wk.k0 + i];
+  __syncthreads();
+  struct Chunk { const float* base; int32_t kk; int kc; uint32_t vA0, vA1; int32_t vB0, vB1; };
+  int32_t kd = wk.k0, kk0 = 0;
+  auto next_chunk = [&]() {
+    const int32_t e = kd - wk.k0;
+    const bool in_table = e < DMAXD;
+    const int32_t d = dense_first + kd;
+    const int32_t c0d = in_table ? t_c0[e] : S.sn_start[d];
+    const int32_t wd = __builtin_amdgcn_readfirstlane((in_table ? t_c0[e + 1] : S.sn_start[d + 1]) - c0d);
+    const int32_t b0d = __builtin_amdgcn_readfirstlane((c0d - c0t) >> 7);
+    Chunk c;
+    c.base = S32 + uniform_i64(in_table ? t_so[e] : soff[d - dense_first]);
+    c.kk = kk0;
+    c.kc = min(KBA, wd - kk0);
+    // float offsets of this lane's rows / columns in k-column 0 of the descendant's shadow (+ the lane's k within a 4-deep block)
+    c.vA0 = (uint32_t)((((gA0 >> 7) - b0d) * wd + lk) * 128 + (gA0 & 127)) * 4u;
+    c.vA1 = (uint32_t)((((gA1 >> 7) - b0d) * wd + lk) * 128 + (gA1 & 127)) * 4u;
+    c.vB0 = (((gB0 >> 7) - b0d) * wd) * 128 + (gB0 & 127);
+    c.vB1 = (((gB1 >> 7) - b0d) * wd) * 128 + (gB1 & 127);
+    kk0 += KBA;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    float* Bs = Bimg + b * KBA * LDBF;
+#pragma unroll
+    for (int i = 0; i < KBA / 8; ++i) {
+      const int kr = wv + 8 * i;
+      const float* col = c.base + (int64_t)(c.kk + kr) * 128;
+      const bool on = kr < c.kc;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? col + c.vB0 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? col + c.vB1 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF + 64), 4, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int s, float (&a)[4][2]) {
+    const int klast = (c.kc - 1) & ~3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const char* sp = (const char*)(c.base + (int64_t)(c.kk + min(16 * s + 4 * q, klast)) * 128);  // wave-uniform
+      a[q][0] = *(const float*)(sp + c.vA0);
+      a[q][1] = *(const float*)(sp + c.vA1);
+    }
+  };
+  d4 acc[NJB][2];
+  f4 c32[NJB][2];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a) {
+    acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0};
+    c32[a][0] = (f4){0.f, 0.f, 0.f, 0.f}; c32[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  float rA[2][4][2];
+  float bf[2][NJB];
+  auto ldB = [&](const float* Bc, int k4, float (&b)[NJB]) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDBF + 16 * jb + li];
+  };
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  bool more = kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  ldB(Bimg, 0, bf[0]);
+  while (true) {
+    const float* Bc = Bimg + buf * KBA * LDBF;
+    const float* Bn = Bimg + (buf ^ 1) * KBA * LDBF;
+    bool more2 = false;
+    Chunk nn = nxt;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+        if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
+      }
+      if (t < 15) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.k1;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        c32[jb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], rA[s & 1][q][0], c32[jb][0], 0, 0, 0);
+        c32[jb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], rA[s & 1][q][1], c32[jb][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // fold the chunk's fp32 sums (64 products each) into the fp64 accumulators
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
@@ -1522,7 +1720,7 @@ __global__ __launch_bounds__(512, 1) void k_dense_s(DevSym S, int32_t dense_firs
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = ia + ib, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+        const int i = ib == 0 ? ia : ib_, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
         const double v = acc[jb][ib][r];
         const int h = i >> 7;
         const int32_t slot = h ? wk.slot1 : wk.slot0;
@@ -1534,11 +1732,188 @@ __global__ __launch_bounds__(512, 1) void k_dense_s(DevSym S, int32_t dense_firs
       }
 }
 
-// Why k_dense_s is here: it tests the explanation given for k_dense_f above.  With operands that are ALREADY fp32 in HBM (half
-// the bytes per flop, no conversions at all) it reaches 86.3 TFLOP/s on the 1M-shaped launch against 83.2 (k_dense32) and 84.5
-// (k_dense_b's streams with fp32 products); with the A fragments fetched two sub-chunks ahead and a partial vmcnt wait at the
-// chunk barrier: 78 (more spills).  So neither the operand bytes nor the conversions nor the load latency explain the 0.55 of
-// the fp32 pipe all four forms share; what does is not found (the register-only / LDS-fed probe sustains 135 - 141 with the
-// same 16 MFMAs, fragment reads and fold per k-step).  Not worth + 50 % tail storage: the engine keeps k_dense32.
+// Why k_dense_t is here: it tested the DRAM-efficiency explanation (contiguous runs instead of 1 KB column pieces): 87.0 TFLOP/s,
+// 88.4 with the descriptor table in LDS -- again the same figure.  A synthetic loop on a launch of the real shape (column-major fp32
+// operands!) sustains 120; the difference was the real kernels' register spills (k_dense_w in csrc/kernels.hip.h).
+
+// ------------------------------------------------------------------------------------------------
+// k_dense_w (RETIRED before it shipped: 69 TFLOP/s -- the compiler spills 59 registers even with the whole file for one wave):
+// the fp32-product dense-tail update with ONE wave per SIMD, a wave owns 64 rows x 128 columns.
+// The four earlier forms (k_dense32 above; three rewrites in csrc/tools/retired_kernels.hip.h) all run at 83 - 88 TFLOP/s, 0.55 of
+// the fp32 matrix pipe, whatever their operand format -- while a synthetic loop with the same operand feeds sustains 114 - 124 on
+// a launch of the real shape (csrc/tools/mfma_f32_feed, mfma_f32_wave64; profiles/r3_mfma_f32_feed.txt).  What the real kernels
+// had and the synthetic loop had not: SPILLS.  Two waves per SIMD leave 256 registers per wave; 128 (fp64 sums) + 64 (fp32 sums)
+// + fragments + addressing do not fit, and the spilled accumulators come back from scratch -- through the same memory pipeline
+// as the 1 - 2 TB/s operand stream -- exactly where the chunk's fold needs them.  With 256-thread workgroups a wave has the
+// whole 512-register file: 256 fp64 + 128 fp32 accumulators (64 x 128 per wave), both fragment sets, no spill; every B fragment
+// feeds four MFMAs instead of two.
+// Operands come from an fp32 SHADOW of the finished tail panels (k_shadow right after a panel's k_trsm; same column-major
+// layout, + 50 % tail storage): half the bytes of the fp64 panels per flop, no conversion in the loop.  Values = k_dense32's
+// operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 64 k; the
+// subtraction from the fp64 panel, k_potrf, k_trsm and the solves stay fp64.  Loop = k_dense_b's: A fragments straight into
+// registers one 16-deep sub-chunk ahead, B image (64 k-rows) by LDS-DMA 4 bytes per lane, fragments prefetched one k-step ahead,
+// one barrier per 64 k; the item's descendants' symbolic entries sit in an LDS table.  Same work items, slabs and epilogue
+// contract as k_dense_b / k_dense32.
+
+constexpr int DW_MAXD = 256;  // descendants per item held in the LDS table (the plan's items have <= 64)
+constexpr size_t dense_w_lds = sizeof(float) * 2 * KBA * LDBF + sizeof(int32_t) * (DW_MAXD + 2) + sizeof(int64_t) * DW_MAXD;
+
+__global__ __launch_bounds__(256, 1) void k_dense_w(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, const float* __restrict__ L32, int64_t base32,
+                                                    double* __restrict__ scratch, const float* __restrict__ zeros32) {
+  static_assert(NB == 128 && DTR == 256, "k_dense_w: 4 waves x 64 rows");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  float* Bimg = (float*)smem;                            // [2][KBA][LDBF]
+  int32_t* t_c0 = (int32_t*)(Bimg + 2 * KBA * LDBF);     // [DW_MAXD + 2]  first columns of the item's descendants
+  int64_t* t_lo = (int64_t*)(t_c0 + DW_MAXD + 2);        // [DW_MAXD]      their panel offsets
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x];
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = wk.ti0 * TM;
+  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
+  if (wk.k0 >= wk.k1) return;
+  const int32_t ndesc = min(wk.k1 - wk.k0, DW_MAXD);
+  for (int i = tid; i <= ndesc; i += 256) t_c0[i] = S.sn_start[dense_first + wk.k0 + i];
+  for (int i = tid; i < ndesc; i += 256) t_lo[i] = S.sn_loff[dense_first + wk.k0 + i];
+  // this lane's four rows inside the item: 64 wv + 16 rb + li (rows past the item's edge: row 0, never stored)
+  uint32_t rowb[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    const int32_t i = 64 * wv + 16 * rb + li;
+    rowb[rb] = (uint32_t)(R0 + (i < nrow ? i : 0)) * 4u;
+  }
+  const int32_t bcol0 = lane < wj ? lane : 0, bcol1 = 64 + lane < wj ? 64 + lane : 0;
+  __syncthreads();
+  struct Chunk { const float* Pd; int32_t md; int kc; };
+  int32_t kd = wk.k0, kk0 = 0;
+  auto next_chunk = [&]() {
+    const int32_t e = kd - wk.k0, d = dense_first + kd;
+    const bool tab = e < DW_MAXD;
+    const int32_t c0d = __builtin_amdgcn_readfirstlane(tab ? t_c0[e] : S.sn_start[d]);
+    const int32_t wd = __builtin_amdgcn_readfirstlane(tab ? t_c0[e + 1] : S.sn_start[d + 1]) - c0d;
+    Chunk c;
+    c.md = S.n - c0d;
+    c.Pd = L32 + (uniform_i64(tab ? t_lo[e] : S.sn_loff[d]) - base32 + (int64_t)kk0 * c.md + (c0j - c0d));
+    c.kc = min(KBA, wd - kk0);
+    kk0 += KBA;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    float* Bs = Bimg + b * KBA * LDBF;
+#pragma unroll
+    for (int i = 0; i < KBA / 4; ++i) {
+      const int kr = wv + 4 * i;
+      const float* row = c.Pd + (int64_t)kr * c.md;
+      const bool on = kr < c.kc;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + bcol0 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_vptr)(on ? row + bcol1 : zeros32 + lane), (lds_vptr)(Bs + kr * LDBF + 64), 4, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int s, float (&a)[4][4]) {
+    const int klast = (c.kc - 1) & ~3;
+    const uint32_t vk = (uint32_t)(lk * c.md) * 4u;  // this lane's k-column inside a 4-deep block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const char* sp = (const char*)(c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md);  // wave-uniform
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a[q][rb] = *(const float*)(sp + (vk + rowb[rb]));
+    }
+  };
+  d4 acc[NJB][4];
+  f4 c32[NJB][4];
+#pragma unroll
+  for (int a = 0; a < NJB; ++a)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) { acc[a][rb] = (d4){0.0, 0.0, 0.0, 0.0}; c32[a][rb] = (f4){0.f, 0.f, 0.f, 0.f}; }
+  float rA[2][4][4];
+  float bf[2][NJB];
+  auto ldB = [&](const float* Bc, int k4, float (&b)[NJB]) {
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDBF + 16 * jb + li];
+  };
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  bool more = kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  ldB(Bimg, 0, bf[0]);
+  while (true) {
+    const float* Bc = Bimg + buf * KBA * LDBF;
+    const float* Bn = Bimg + (buf ^ 1) * KBA * LDBF;
+    bool more2 = false;
+    Chunk nn = nxt;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+        if (s < 3) load_A(cur, s + 1, rA[(s + 1) & 1]);
+        else if (more) load_A(nxt, 0, rA[0]);
+      }
+      if (t < 15) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        // chunk boundary: every wave has READ its last fragments of Bc (they are in registers) and the copy of the next
+        // chunk has landed -- after this barrier Bn may be read and Bc overwritten
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.k1;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+          c32[jb][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t & 1][jb], rA[s & 1][q][rb], c32[jb][rb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // fold the chunk's fp32 sums (64 products each) into the fp64 accumulators
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jb][rb][r] += (double)c32[jb][rb][r];
+        c32[jb][rb] = (f4){0.f, 0.f, 0.f, 0.f};
+      }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 64 * wv + 16 * rb + li, jc = 16 * jb + 4 * lk + r;  // fp32 MFMA layout: M = 4 (l >> 4) + r
+        const double v = acc[jb][rb][r];
+        const int h = i >> 7;
+        const int32_t slot = h ? wk.slot1 : wk.slot0;
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else if (h < wk.ntiles) {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
+        }
+      }
+}
+
 
 }  // namespace scilmm
