@@ -187,7 +187,9 @@ int scilmm_selected_inverse(scilmm_factor* fac);
 int scilmm_inverse_traces(scilmm_factor* fac, double* out);
 
 /* BASELINE configs[4] ("fp64 factor with fp32 MFMA fronts"): bits = 32 runs the products of the dense-tail update on
- * the fp32 matrix pipe (operands rounded to fp32 in LDS, every 16-deep chunk summed in fp32, chunks summed in fp64);
+ * the fp32 matrix pipe: the finished tail panels get an fp32 shadow (one rounding per entry; + 50 % tail storage, dropped when
+ * the device has no room for it or the tail is distributed: the operands are then rounded while they are staged), products are
+ * summed in fp32 over 128 (staged form: 16) of them and those sums in fp64;
  * everything else -- the subtraction from the panel, potrf, trsm, the solves -- stays fp64.  The factor then has a
  * relative backward error of ~1e-7: callers refine their solves against the exact V (scilmm_spmm), as
  * scilmm_amd.factor.Factor does.  bits = 64 (default) restores the all-fp64 path.  No counterpart in the reference. */
@@ -230,7 +232,7 @@ typedef struct scilmm_timing {
   /* wall time during which at least one update launch was running (early launches of consecutive levels
    * overlap on the two side streams, so update_ms -- the SUM of launch durations -- counts that time twice) */
   double update_union_ms;
-  /* the dense-tail kernel alone (k_dense / k_dense32): summed launch durations and launch count of the last factorize */
+  /* the dense-tail kernel alone (k_dense_b / k_dense_h / k_dense32): summed launch durations and launch count of the last factorize */
   double dense_ms;
   int64_t n_dense_launches;
 } scilmm_timing;
