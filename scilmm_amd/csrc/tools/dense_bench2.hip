@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)k_dense_t, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_dense_w, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   CK(hipFuncSetAttribute((const void*)k_dense_h, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  CK(hipFuncSetAttribute((const void*)k_dense_q, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   float* L32;
   CK(hipMalloc(&L32, sizeof(float) * ((size_t)nL + 16384)));
   CK(hipMemset(L32, 0, sizeof(float) * ((size_t)nL + 16384)));
@@ -97,13 +98,14 @@ int main(int argc, char** argv) {
          work.size(), per, flops / 1e12, SCILMM_DENSE_B_SG, 0);
   const size_t smb = sizeof(double) * 2 * KBA * LDB;
   for (int fill : {0, 1})
-  for (int which : {1, 3, 7}) {
+  for (int which : {1, 8, 3, 7}) {
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, L, nL, fill);
     for (int rep = 0; rep < 4; ++rep) {
       hipEventRecord(e0);
       if (which == 0) hipLaunchKernelGGL(k_dense_a, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else if (which == 1) hipLaunchKernelGGL(k_dense_b, dim3((unsigned)work.size()), dim3(512), smb, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else if (which == 2) hipLaunchKernelGGL(k_dense_f, dim3((unsigned)work.size()), dim3(512), dense_f_lds, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      else if (which == 8) hipLaunchKernelGGL(k_dense_q, dim3(2 * (unsigned)work.size()), dim3(512), dense_q_lds, 0, S, 0, d_work, L, scratch, (const double*)zeros);
       else if (which == 7) {
         if (rep == 0) hipLaunchKernelGGL(k_shadow, dim3(8192), dim3(256), 0, 0, (const double*)L, L32, (int64_t)nL);
         hipEventRecord(e0);
@@ -132,7 +134,7 @@ int main(int argc, char** argv) {
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       CK(hipGetLastError());
-      if (rep) printf("%s, %s operands: %.3f ms -> %.2f TFLOP/s\n", which == 0 ? "k_dense_a" : which == 1 ? "k_dense_b" : which == 2 ? "k_dense_f (fp32 products)" : which == 4 ? "k_dense_s (fp32 shadow operands)" : which == 5 ? "k_dense_t (tile-major fp32 shadow)" : which == 6 ? "k_dense_w (one wave per SIMD, fp32 shadow)" : which == 7 ? "k_dense_h (32 x 64 wave tiles, fp32 shadow)" : "k_dense32 (round 2)", fill ? "random" : "zero", ms, flops / ms / 1e9);
+      if (rep) printf("%s, %s operands: %.3f ms -> %.2f TFLOP/s\n", which == 0 ? "k_dense_a" : which == 1 ? "k_dense_b" : which == 2 ? "k_dense_f (fp32 products)" : which == 4 ? "k_dense_s (fp32 shadow operands)" : which == 5 ? "k_dense_t (tile-major fp32 shadow)" : which == 6 ? "k_dense_w (one wave per SIMD, fp32 shadow)" : which == 7 ? "k_dense_h (32 x 64 wave tiles, fp32 shadow)" : which == 8 ? "k_dense_q (fp64, 32 x 64 wave tiles, two workgroups per CU)" : "k_dense32 (round 2)", fill ? "random" : "zero", ms, flops / ms / 1e9);
     }
   }
   {
@@ -157,9 +159,11 @@ int main(int argc, char** argv) {
     double mx = 0, ref = 0;
     for (size_t i = 0; i < ns; ++i) if (live[i]) { mx = std::max(mx, std::fabs(r0[i] - r1[i])); ref = std::max(ref, std::fabs(r0[i])); }
     printf("k_dense_b vs k_dense_a: max |difference| of the slabs %.3g (largest entry %.3g)\n", mx, ref);
-    for (int v = 0; v < 6; ++v) {
+    for (int v = 0; v < 7; ++v) {
       CK(hipMemset(scratch, 0, sizeof(double) * ns));
-      if (v == 5) {
+      if (v == 6) {
+        hipLaunchKernelGGL(k_dense_q, dim3(2 * (unsigned)work.size()), dim3(512), dense_q_lds, 0, S, 0, d_work, L, scratch, (const double*)zeros);
+      } else if (v == 5) {
         hipLaunchKernelGGL(k_shadow, dim3(8192), dim3(256), 0, 0, (const double*)L, L32, (int64_t)nL);
         hipLaunchKernelGGL(k_dense_h, dim3(2 * (unsigned)work.size()), dim3(512), dense_h_lds, 0, S, 0, d_work, L, (const float*)L32, (int64_t)0, scratch, (const float*)zeros);
       } else if (v == 4) {
@@ -177,7 +181,7 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(r1.data(), scratch, sizeof(double) * ns, hipMemcpyDeviceToHost));
       mx = 0;
       for (size_t i = 0; i < ns; ++i) if (live[i]) mx = std::max(mx, std::fabs(r0[i] - r1[i]));
-      printf("%s vs fp64: max |difference| of the slabs %.3g (largest entry %.3g)\n", v == 5 ? "k_dense_h (32 x 64 wave tiles, fp32 shadow)" : v == 4 ? "k_dense_w (one wave per SIMD, fp32 shadow)" : v == 3 ? "k_dense_t (tile-major fp32 shadow)" : v == 2 ? "k_dense_s (fp32 shadow operands)" : v ? "k_dense32 (round 2)" : "k_dense_f (fp32 products)", mx, ref);
+      printf("%s vs fp64: max |difference| of the slabs %.3g (largest entry %.3g)\n", v == 6 ? "k_dense_q (fp64, 32 x 64 wave tiles)" : v == 5 ? "k_dense_h (32 x 64 wave tiles, fp32 shadow)" : v == 4 ? "k_dense_w (one wave per SIMD, fp32 shadow)" : v == 3 ? "k_dense_t (tile-major fp32 shadow)" : v == 2 ? "k_dense_s (fp32 shadow operands)" : v ? "k_dense32 (round 2)" : "k_dense_f (fp32 products)", mx, ref);
     }
   }
   return 0;

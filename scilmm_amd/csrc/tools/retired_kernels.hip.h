@@ -1916,4 +1916,152 @@ __global__ __launch_bounds__(256, 1) void k_dense_w(DevSym S, int32_t dense_firs
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// k_dense_q (RETIRED before it shipped: 63.6 TFLOP/s against k_dense_b's 68.0 on the 1M-shaped launch, bit-identical slabs --
+// the fp64 kernel is not short of latency hiding, so smaller wave tiles only add fragment traffic and barriers):
+// k_dense_h's tiling for the fp64 kernel: a wave owns
+// 32 rows x 64 columns (64 registers of sums instead of k_dense_b's 128), B chunks of 32 k-rows (two 36 KB buffers), so that two
+// workgroups share a CU.  Two workgroups serve one work item.  Same operands, same products as k_dense_b; the sum ORDER inside an
+// item is the same too (k ascending), so the slabs are bit-identical.
+constexpr int KQ = 32;
+constexpr size_t dense_q_lds = sizeof(double) * 2 * KQ * LDB + sizeof(int32_t) * (DH_MAXD + 2) + sizeof(int64_t) * DH_MAXD;
+
+__global__ __launch_bounds__(512, 4) void k_dense_q(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
+                                                    double* __restrict__ L, double* __restrict__ scratch,
+                                                    const double* __restrict__ zeros) {
+  static_assert(NB == 128 && TM == 128, "k_dense_q: 4 x 2 waves of 32 rows x 64 columns");
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [2][KQ][LDB]
+  int32_t* t_c0 = (int32_t*)(smem + 2 * KQ * LDB);
+  int64_t* t_lo = (int64_t*)(t_c0 + DH_MAXD + 2);
+  constexpr int NJH = NJB / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wv >> 1, ch = wv & 1;
+  const int li = lane & 15, lk = lane >> 4;
+  const DenseWork wk = work[blockIdx.x >> 1];
+  const int th = blockIdx.x & 1;
+  if (th >= wk.ntiles || wk.k0 >= wk.k1) return;
+  const int32_t j = wk.front;
+  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
+  const int32_t mj = S.n - c0j;
+  const int32_t R0 = (wk.ti0 + th) * TM;
+  const int32_t nrow = min(TM, mj - R0);
+  const int32_t slot = th ? wk.slot1 : wk.slot0;
+  const int32_t ndesc = min(wk.k1 - wk.k0, DH_MAXD);
+  for (int i = tid; i <= ndesc; i += 512) t_c0[i] = S.sn_start[dense_first + wk.k0 + i];
+  for (int i = tid; i < ndesc; i += 512) t_lo[i] = S.sn_loff[dense_first + wk.k0 + i];
+  const int32_t ia = 32 * rg + li, ib_ = ia + 16;
+  const int32_t ra0 = R0 + (ia < nrow ? ia : 0), ra1 = R0 + (ib_ < nrow ? ib_ : 0);
+  const int32_t b_off = 2 * lane < wj ? 2 * lane : 0;
+  const double* zsrc = zeros + 2 * lane;
+  __syncthreads();
+  struct Chunk { const double* Pd; int32_t md; int kc; };
+  int32_t kd = wk.k0, kk0 = 0;
+  auto next_chunk = [&]() {
+    const int32_t e = kd - wk.k0, d = dense_first + kd;
+    const bool tab = e < DH_MAXD;
+    const int32_t c0d = __builtin_amdgcn_readfirstlane(tab ? t_c0[e] : S.sn_start[d]);
+    const int32_t wd = __builtin_amdgcn_readfirstlane(tab ? t_c0[e + 1] : S.sn_start[d + 1]) - c0d;
+    Chunk c;
+    c.md = S.n - c0d;
+    c.Pd = L + (uniform_i64(tab ? t_lo[e] : S.sn_loff[d]) + (int64_t)kk0 * c.md + (c0j - c0d));
+    c.kc = min(KQ, wd - kk0);
+    kk0 += KQ;
+    if (kk0 >= wd) { kk0 = 0; ++kd; }
+    return c;
+  };
+  auto issue_B = [&](const Chunk& c, int b) {
+    double* Bs = smem + b * KQ * LDB;
+#pragma unroll
+    for (int i = 0; i < KQ / 8; ++i) {
+      const int kr = wv + 8 * i;
+      __builtin_amdgcn_global_load_lds((gl_vptr)(kr < c.kc ? c.Pd + (int64_t)kr * c.md + b_off : zsrc), (lds_vptr)(Bs + kr * LDB), 16, 0, 0);
+    }
+  };
+  auto load_A = [&](const Chunk& c, int s, double (&a)[4][2]) {
+    const int klast = (c.kc - 1) & ~3;
+    const uint32_t v0 = (uint32_t)(lk * c.md + ra0) * 8u, v1 = (uint32_t)(lk * c.md + ra1) * 8u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* sp = c.Pd + (int64_t)min(16 * s + 4 * q, klast) * c.md;  // wave-uniform
+      a[q][0] = ld_off(sp, v0);
+      a[q][1] = ld_off(sp, v1);
+    }
+  };
+  d4 acc[NJH][2];
+#pragma unroll
+  for (int a = 0; a < NJH; ++a) { acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
+  double rA[2][4][2];
+  double bf[2][NJH];
+  auto ldB = [&](const double* Bc, int k4, double (&b)[NJH]) {
+#pragma unroll
+    for (int jb = 0; jb < NJH; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 64 * ch + 16 * jb + li];
+  };
+  Chunk cur = next_chunk();
+  issue_B(cur, 0);
+  load_A(cur, 0, rA[0]);
+  bool more = kd < wk.k1;
+  Chunk nxt = cur;
+  if (more) {
+    nxt = next_chunk();
+    issue_B(nxt, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  ldB(smem, 0, bf[0]);
+  while (true) {
+    const double* Bc = smem + buf * KQ * LDB;
+    const double* Bn = smem + (buf ^ 1) * KQ * LDB;
+    bool more2 = false;
+    Chunk nn = nxt;
+#pragma unroll
+    for (int t = 0; t < KQ / 4; ++t) {
+      const int s = t >> 2, q = t & 3;
+      if (q == 0) {
+        if (s == 0) load_A(cur, 1, rA[1]);
+        else if (more) load_A(nxt, 0, rA[0]);
+      }
+      if (t < KQ / 4 - 1) {
+        ldB(Bc, 4 * (t + 1), bf[(t + 1) & 1]);
+      } else if (more) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ldB(Bn, 0, bf[0]);
+        more2 = kd < wk.k1;
+        if (more2) {
+          nn = next_chunk();
+          issue_B(nn, buf);
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < NJH; ++jb) {
+        acc[jb][0] = mfma_f64(bf[t & 1][jb], rA[s & 1][q][0], acc[jb][0]);
+        acc[jb][1] = mfma_f64(bf[t & 1][jb], rA[s & 1][q][1], acc[jb][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!more) break;
+    cur = nxt;
+    nxt = nn;
+    more = more2;
+    buf ^= 1;
+  }
+  double* P = L + S.sn_loff[j];
+#pragma unroll
+  for (int jb = 0; jb < NJH; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib == 0 ? ia : ib_, jc = 64 * ch + 16 * jb + lk + 4 * r;
+        const double v = acc[jb][ib][r];
+        if (slot < 0) {
+          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
+        } else {
+          scratch[(int64_t)slot * (TM * NB) + jc * TM + i] = v;
+        }
+      }
+}
+
+
 }  // namespace scilmm
