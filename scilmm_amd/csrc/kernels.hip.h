@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512, 1) void k_dense32(DevSym S, int32_t dense_firs
 // group load the same A rows (the second load hits L1 / L2).
 // Operands come from an fp32 SHADOW of the finished tail panels (k_shadow right after a panel's k_trsm; same column-major
 // layout, + 50 % tail storage): half the bytes of the fp64 panels per flop, no conversion in the loop.  Values = k_dense32's
-// operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 64 k; the
+// operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 128 k; the
 // subtraction from the fp64 panel, k_potrf, k_trsm and the solves stay fp64.  Loop = k_dense_b's: A fragments (a lane's two
 // adjacent rows, one 8-byte load per k) straight into registers one 16-deep sub-chunk ahead, B image (64 k-rows x 128 columns)
 // by LDS-DMA 4 bytes per lane, fragments prefetched one k-step ahead, one barrier per 64 k; the item's descendants' symbolic
@@ -961,10 +961,12 @@ __global__ __launch_bounds__(512, SCILMM_DENSE_H_WGS) void k_dense_h(DevSym S, i
       }
 #ifndef SCILMM_DENSE_H_NOFOLD  // (fold experiment of csrc/tools/dense_bench2: fp32 sums over the whole item, WRONG error model)
       if (t == 15 && (cidx & (SCILMM_DENSE_H_FOLD - 1)) == SCILMM_DENSE_H_FOLD - 1) {
-        // fold the fp32 sums into the fp64 accumulators every SCILMM_DENSE_H_FOLD chunks of 64 k.  The fold is ~100 double-
-        // precision vector instructions per wave, and on gfx950 the fp32 matrix instructions run at the fp32 VECTOR rate: the
-        // kernel alone runs at 117 TFLOP/s without any fold, 95.7 folding every chunk -- whether the two waves of a SIMD fold
-        // at the same k-step or eight k-steps apart (92.6): the fold's time ADDS to the products'.
+        // fold the fp32 sums into the fp64 accumulators every SCILMM_DENSE_H_FOLD chunks of 64 k.  Between two folds the fp64
+        // accumulators are dead weight: at the 128-register budget of two workgroups per CU the compiler parks part of them in
+        // scratch and fetches them here, so the fold period sets the price (alone, 1M-shaped launch: 64 / 128 / 256 / 512 k =
+        // 72 / 103.7 / 110.9 / 114.1 TFLOP/s, no fold at all 117; error of a 6144-deep item against fp64 at entries of 2e3:
+        // 9e-5 / 2.1e-4 / 4.6e-4 / 6.9e-4).  At one workgroup per CU (156 registers, nothing spilled) the period hardly
+        // matters (94.5 ... 98.0) and staggering the two waves of a SIMD by eight k-steps does not help (92.6).
 #pragma unroll
         for (int jb = 0; jb < NJH; ++jb)
 #pragma unroll
