@@ -48,6 +48,7 @@ struct Dev {
   bool use_mfma = true;
   hipEvent_t ev[8];
   scilmm_timing timing{};
+  bool quad_pending = false;           // a scilmm_quadforms_dev call whose timer has not been read yet
   bool attrs_set = false;
   // update-kernel plan: flattened combo descriptors, per-level work items (split-K), partial slots
   ComboDesc* d_combos = nullptr;
@@ -1745,15 +1746,16 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
   hipStream_t st = D->stream;
   int64_t launches = 0;
   {
-    // front precision 32 on one GPU: the dense-tail kernel reads an fp32 shadow of the finished tail panels (k_dense_h).  It
-    // is allocated with the first such factorization and kept (zeroed once: the kernel may read a few entries past a panel,
-    // into the next panel's or the slack's, which must be finite); a distributed tail keeps k_dense32 (fp64 operands: the
-    // ring slots have no shadow), and so does a device without room for it.  SCILMM_TUNING=1 SCILMM_SHADOW=0: k_dense32.
+    // front precision 32: the dense-tail kernel reads an fp32 shadow of the finished tail panels (k_dense_h) -- of the rank's own
+    // panels and of its ring slots when the tail is distributed (same rank-local offsets as L, minus the prelude).  It is
+    // allocated with the first such factorization and kept (zeroed once: the kernel may read a few entries past a panel, into
+    // the next panel's or the slack's, which must be finite); a device without room for it keeps k_dense32 (fp64 operands
+    // rounded while they are staged).  SCILMM_TUNING=1 SCILMM_SHADOW=0: k_dense32.
     const char* esh = tune_env("SCILMM_SHADOW");
-    const bool want = D->front_bits == 32 && D->dense_on && !dist && !(esh && esh[0] == '0');
+    const bool want = D->front_bits == 32 && D->dense_on && !(esh && esh[0] == '0');
     if (want && !fac->L32) {
-      fac->base32 = S.sn_loff[S.dense_first];
-      const size_t cnt32 = (size_t)(S.sn_loff[S.nsuper] - fac->base32) + 16384;
+      fac->base32 = S.sn_loff[S.dense_first];  // (= the prelude's size: the prelude is replicated and stored first on every rank)
+      const size_t cnt32 = (size_t)(D->nL_local - fac->base32) + 16384;
       if (hipMalloc((void**)&fac->L32, sizeof(float) * cnt32) != hipSuccess) {
         (void)hipGetLastError();
         fac->L32 = nullptr;
@@ -1956,11 +1958,11 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       // front precision 32: the level's finished tail panel -> its fp32 shadow, before the level's event (the look-ahead
       // launches of later targets read the shadow only)
       for (int32_t q = f0; q < f1; ++q) {
-        const int32_t fr = S.level_fronts[q];
-        if (fr < S.dense_first) continue;
+        const int32_t fr = D->lv_fronts[(size_t)q];  // (the level's fronts THIS rank holds: another rank's panel is shadowed when it arrives, below)
+        if (fr < S.dense_first || !D->keep_front[fr]) continue;
         const int64_t cnt = S.sn_loff[fr + 1] - S.sn_loff[fr];
         hipLaunchKernelGGL(k_shadow, dim3((unsigned)std::min<int64_t>((cnt + 255) / 256, 8192)), dim3(256), 0, st,
-                           (const double*)(fac->L + S.sn_loff[fr]), fac->L32 + (S.sn_loff[fr] - fac->base32), cnt);
+                           (const double*)(fac->L + D->loff[fr]), fac->L32 + (D->loff[fr] - fac->base32), cnt);
         launches++;
       }
     }
@@ -1994,6 +1996,12 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       if (rcm != 0) {
         sym->err = "multi-GPU: the communication callback failed";
         return SCILMM_ERR_DEVICE;
+      }
+      if (fac->L32 && !D->keep_front[tf]) {
+        // front precision 32: the arrived panel's fp32 shadow, on the communication stream behind the broadcast
+        hipLaunchKernelGGL(k_shadow, dim3((unsigned)std::min<int64_t>((pm * pw + 255) / 256, 8192)), dim3(256), 0, D->comm,
+                           (const double*)(fac->L + D->loff[tf]), fac->L32 + (D->loff[tf] - fac->base32), pm * pw);
+        launches++;
       }
       HIPCHK(hipEventRecord(D->lev_ev[2 * l], D->comm));
       last_tail_level = l;
@@ -2791,7 +2799,9 @@ int scilmm_quadforms_dev(scilmm_symbolic* sym, int32_t k, const double* dU, int3
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
-  return run_quad(sym, D, k, dU, r, d_out);
+  st = run_quad(sym, D, k, dU, r, d_out);
+  D->quad_pending = st == SCILMM_OK;  // (asynchronous: scilmm_last_timing reads the events once they have happened)
+  return st;
 }
 
 int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r, double* out) {
@@ -3231,7 +3241,15 @@ int scilmm_sync(scilmm_symbolic* sym) {
 
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out) {
   if (!sym || !sym->device || !out) return SCILMM_ERR_ARG;
-  *out = ((Dev*)sym->device)->timing;
+  Dev* D = (Dev*)sym->device;
+  if (D->quad_pending) {
+    // the device-pointer form of the quadratic forms returns without waiting: its timer (the LAST call's) is read here
+    DevGuard guard(const_cast<scilmm_symbolic*>(sym));
+    float q = 0;
+    if (hipEventSynchronize(D->ev[7]) == hipSuccess && hipEventElapsedTime(&q, D->ev[6], D->ev[7]) == hipSuccess) D->timing.quad_ms = q;
+    D->quad_pending = false;
+  }
+  *out = D->timing;
   return SCILMM_OK;
 }
 

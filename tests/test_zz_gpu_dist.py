@@ -43,6 +43,8 @@ def _worker(rank, world, port, out, env):
     from scilmm_amd.dist import DistributedEvaluator, HipChainEngine, tail_layout
     mats, C, y = _problem()
     eng = HipChainEngine(mats, rank, world, dist, "cuda:0")
+    if os.environ.get("SCILMM_TEST_FRONT_BITS") == "32":
+        eng.sym.set_front_precision(32)   # configs[4]'s arithmetic: fp32-product fronts (fp32 shadow of own panels + ring slots)
     ev = DistributedEvaluator(eng, mats, C, y, rank, world, dist, device="cpu")
     np.random.seed(4)
     nll, grad = ev.evaluate(np.log([0.45, 0.5]), reml=True, sim_num=50)
@@ -92,6 +94,33 @@ def test_ranks_sharing_one_gpu_match_single_process(tmp_path, world, env):
         assert rel_err(g["Z2"], f2.lmul(B)) < 1e-10
         first, Wg, G = (int(v) for v in g["params"])
         assert int(g["nsuper"]) - first == 24 and Wg % world == 0 and G == 4 * Wg
+
+
+def test_distributed_tail_with_fp32_product_fronts(tmp_path):
+    """BASELINE configs[4]'s arithmetic on the multi-rank path: fp32-product fronts (k_dense_h on the fp32 shadow of a rank's own
+    panels AND of its ring slots, written when a panel arrives) against the fp64 single-process factor, at the accuracy the
+    fp32 products allow (the callers' refinement is not part of the distributed sweeps)."""
+    import torch.multiprocessing as mp
+    from scilmm_amd.factor import Symbolic
+    world = 2
+    out = str(tmp_path / "rank%d.npz")
+    env = {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "2", "SCILMM_TEST_FRONT_BITS": "32"}
+    mp.spawn(_worker, args=(world, _free_port(), out, env), nprocs=world, join=True)
+    got = [np.load(out % r) for r in range(world)]
+    mats, C, y = _problem()
+    sym = Symbolic(mats)
+    f = sym.factorize([0.45, 0.5])
+    B = np.random.default_rng(0).standard_normal((y.size, 7))
+    X = f(B)
+    f2 = sym.factorize([0.3, 0.7])
+    for g in got:
+        assert abs(g["logdet"] - f.logdet()) < 1e-6 * abs(f.logdet())
+        assert rel_err(g["X"], X) < 1e-5
+        assert abs(g["logdet"] - f.logdet()) > 1e-9          # (not the fp64 factor: the fp32 products did run)
+        assert abs(g["logdet2"] - f2.logdet()) < 1e-6 * abs(f2.logdet())
+        assert rel_err(g["X2"], f2(B)) < 1e-5 and rel_err(g["Z2"], f2.lmul(B)) < 1e-5
+    # every rank ends with the same result (to rounding: the replicated prelude sums its tail contributions with atomics)
+    assert rel_err(got[0]["X"], got[1]["X"]) < 1e-12 and abs(got[0]["logdet"] - got[1]["logdet"]) < 1e-10 * abs(got[0]["logdet"])
 
 
 def _npd_worker(rank, world, port, out):
