@@ -187,8 +187,9 @@ int scilmm_selected_inverse(scilmm_factor* fac);
 int scilmm_inverse_traces(scilmm_factor* fac, double* out);
 
 /* BASELINE configs[4] ("fp64 factor with fp32 MFMA fronts"): bits = 32 runs the products of the dense-tail update on
- * the fp32 matrix pipe: the finished tail panels get an fp32 shadow (one rounding per entry; + 50 % tail storage, dropped when
- * the device has no room for it or the tail is distributed: the operands are then rounded while they are staged), products are
+ * the fp32 matrix pipe: the finished tail panels get an fp32 shadow (one rounding per entry; + 50 % tail storage -- of a rank's own
+ * panels and ring slots when the tail is distributed --, dropped when the device has no room for it: the operands are then
+ * rounded while they are staged), products are
  * summed in fp32 over 128 (staged form: 16) of them and those sums in fp64;
  * everything else -- the subtraction from the panel, potrf, trsm, the solves -- stays fp64.  The factor then has a
  * relative backward error of ~1e-7: callers refine their solves against the exact V (scilmm_spmm), as

@@ -815,8 +815,8 @@ __global__ __launch_bounds__(512, 1) void k_dense32(DevSym S, int32_t dense_firs
 // workgroup tile 4 x 2 -- so the sums take 64 + 32 registers and nothing spills.  Two workgroups serve one work item (its two
 // 128-row tiles); HBM bytes per flop are unchanged (they depend on the columns per workgroup), the two column halves of a row
 // group load the same A rows (the second load hits L1 / L2).
-// Operands come from an fp32 SHADOW of the finished tail panels (k_shadow right after a panel's k_trsm; same column-major
-// layout, + 50 % tail storage): half the bytes of the fp64 panels per flop, no conversion in the loop.  Values = k_dense32's
+// Operands come from an fp32 SHADOW of the finished tail panels (k_shadow right after a panel's k_trsm, and behind the broadcast
+// of a panel that arrives from another rank; same column-major layout and rank-local offsets, + 50 % tail storage): half the bytes of the fp64 panels per flop, no conversion in the loop.  Values = k_dense32's
 // operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 128 k; the
 // subtraction from the fp64 panel, k_potrf, k_trsm and the solves stay fp64.  Loop = k_dense_b's: A fragments (a lane's two
 // adjacent rows, one 8-byte load per k) straight into registers one 16-deep sub-chunk ahead, B image (64 k-rows x 128 columns)
