@@ -467,7 +467,7 @@ def main():
             # dominant kernel = k_dense: ITS algorithmic flops (tail x tail updates, true structure) over ITS launches
             kern = (("k_dense32 (fp32 products, fp64 sums: update of the dense tail by the dense tail, fp64 operands)"
                      if os.environ.get("SCILMM_SHADOW") == "0" else
-                     "k_dense_h (fp32 products out of an fp32 shadow of the tail panels, fp64 sums every 128 k: update of the dense "
+                     "k_dense_h (fp32 products out of an fp32 shadow of the tail panels, fp64 sums every 256 k: update of the dense "
                      "tail by the dense tail)") if args.front_bits == 32 else
                     "k_dense_b (fp64 MFMA update of the dense tail by the dense tail: A fragments from registers, B by LDS-DMA, "
                     "both streams software-pipelined in the wave)")

@@ -190,7 +190,7 @@ int scilmm_inverse_traces(scilmm_factor* fac, double* out);
  * the fp32 matrix pipe: the finished tail panels get an fp32 shadow (one rounding per entry; + 50 % tail storage -- of a rank's own
  * panels and ring slots when the tail is distributed --, dropped when the device has no room for it: the operands are then
  * rounded while they are staged), products are
- * summed in fp32 over 128 (staged form: 16) of them and those sums in fp64;
+ * summed in fp32 over 256 (staged form: 16) of them and those sums in fp64;
  * everything else -- the subtraction from the panel, potrf, trsm, the solves -- stays fp64.  The factor then has a
  * relative backward error of ~1e-7: callers refine their solves against the exact V (scilmm_spmm), as
  * scilmm_amd.factor.Factor does.  bits = 64 (default) restores the all-fp64 path.  No counterpart in the reference. */

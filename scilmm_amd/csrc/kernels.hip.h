@@ -817,7 +817,7 @@ __global__ __launch_bounds__(512, 1) void k_dense32(DevSym S, int32_t dense_firs
 // group load the same A rows (the second load hits L1 / L2).
 // Operands come from an fp32 SHADOW of the finished tail panels (k_shadow right after a panel's k_trsm, and behind the broadcast
 // of a panel that arrives from another rank; same column-major layout and rank-local offsets, + 50 % tail storage): half the bytes of the fp64 panels per flop, no conversion in the loop.  Values = k_dense32's
-// operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 128 k; the
+// operands (one rounding of the finished fp64 entry); products on the fp32 matrix pipe; sums folded into fp64 every 256 k; the
 // subtraction from the fp64 panel, k_potrf, k_trsm and the solves stay fp64.  Loop = k_dense_b's: A fragments (a lane's two
 // adjacent rows, one 8-byte load per k) straight into registers one 16-deep sub-chunk ahead, B image (64 k-rows x 128 columns)
 // by LDS-DMA 4 bytes per lane, fragments prefetched one k-step ahead, one barrier per 64 k; the item's descendants' symbolic
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void k_shadow(const double* __restrict__ src, 
 }
 
 #ifndef SCILMM_DENSE_H_FOLD
-#define SCILMM_DENSE_H_FOLD 2   // chunks of 64 k between two folds of the fp32 sums into the fp64 accumulators (a power of two)
+#define SCILMM_DENSE_H_FOLD 4   // chunks of 64 k between two folds of the fp32 sums into the fp64 accumulators (a power of two)
 #endif
 #ifndef SCILMM_DENSE_H_WGS
 #define SCILMM_DENSE_H_WGS 4    // waves per SIMD the register budget is cut for (4 = two workgroups per CU: 128 registers per wave)
