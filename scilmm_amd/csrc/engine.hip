@@ -3096,7 +3096,16 @@ int scilmm_selected_inverse(scilmm_factor* fac) {
       const int32_t count = S.nsuper - 1 - f;  // later fronts
       if (u > 0 && count > 0) {
         const int64_t ntile = (u + 255) / 256;
-        const int32_t nseg = (int32_t)std::max<int64_t>(1, std::min<int64_t>(count, 1024 / ntile));
+        // about 1024 items per front, and a count that fills the last round of 256 workgroups: the fronts' launches follow
+        // each other on one stream, so I items cost ceil(I / 256) rounds with nothing to fill the gap
+        const int64_t base = std::max<int64_t>(1, std::min<int64_t>(count, 1024 / ntile));
+        int32_t nseg = (int32_t)base;
+        double best = -1.0;
+        for (int64_t c = std::max<int64_t>(1, base / 2); c <= std::min<int64_t>(count, 2 * base + 1); ++c) {
+          const int64_t items = ntile * c, rounds = (items + 255) / 256;
+          const double score = (double)items / (double)(rounds * 256) - 0.02 * std::fabs((double)(c - base)) / (double)base;
+          if (score > best) { best = score; nseg = (int32_t)c; }
+        }
         for (int32_t sg = 0; sg < nseg; ++sg) {
           const int32_t ka = f + 1 + (int32_t)((int64_t)count * sg / nseg), kb = f + 1 + (int32_t)((int64_t)count * (sg + 1) / nseg);
           if (kb <= ka) continue;
