@@ -346,6 +346,10 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
             cols.append((invV_C[:, a] + invV_C[:, b])[:, None])
     Q = np.ascontiguousarray(np.hstack(cols))
     grad = np.zeros(len(sig2g_array))
+    if exact and getattr(cholesky_func, '_before_traces', None) is not None:
+        # (the selected inverse CONSUMES the factor: whatever else needs solves at this sigma2 -- the AI matrix of _ai_reml --
+        # runs here, between the evaluation's own sweep and the inverse)
+        cholesky_func._hook_result = cholesky_func._before_traces(fac)
     traces = _exact_traces(fac, mats) if exact else None
     for k in range(len(sig2g_array)):
         q = sym.quadforms(k, Q)
@@ -419,7 +423,14 @@ def estimate_var_comps(cholesky_func, mats, covariates, y, reml=True, sim_num=10
         x0 = np.ones((len(mats)))
     x0 = x0 / x0.sum()
     if aireml:
-        return _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose)
+        s2 = _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose)
+        if not (_is_hip(cholesky_func) and getattr(cholesky_func, 'exact_trace', False)):
+            return s2
+        # exact traces make the objective deterministic, so the end point can be CHECKED: the average-information step can
+        # stall next to a boundary the likelihood is flat along (a component pulled towards zero iteration after iteration);
+        # the reference's optimiser then finishes the job from where the iteration stopped -- it returns at once when that
+        # point already is stationary
+        x0 = np.maximum(s2, 1e-8 * s2.sum())
     optObj = optimize.minimize(bolt_gradient_estimation, np.log(x0),
                                args=(cholesky_func, mats, covariates, y, reml, sim_num, verbose, True),
                                jac=True, method='L-BFGS-B', options={'eps': 1e-5, 'ftol': 1e-7})
@@ -436,22 +447,19 @@ def _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose, max
     with P y = V^-1 (y - C beta).  The gradient comes from ONE call of ``bolt_gradient_estimation`` (take_exp=False): the
     same factorization, fused sweep and Monte-Carlo -- or, with ``SparseCholesky(exact_trace=True)``, exact -- trace as the
     L-BFGS-B path; the AI matrix costs K more single-column solves on the factor that evaluation left resident.  Steps are
-    halved until every component stays positive and the likelihood does not rise.  The Monte-Carlo trace uses COMMON
+    halved until the likelihood does not rise (or the Newton decrement falls); a component a step would drive through zero is
+    pulled to a tenth of its value instead.  The Monte-Carlo trace uses COMMON
     random numbers: every evaluation of the fit restarts np.random from the state it had on entry (the probe vectors
     are the same at every sigma2, as in BOLT-REML), so the objective is one smooth function and the iteration converges
     like a Newton method instead of wandering inside the estimator's noise; on return the stream has advanced by one
     evaluation.  Stops on the reference's L-BFGS-B tolerance (relative likelihood change <= 1e-7) or a relative step
-    below ``tol``.  Opt-in: ``REML(..., aireml=True)``; the default optimiser stays the reference's L-BFGS-B."""
+    below ``tol``.  With exact traces (deterministic objective) ``estimate_var_comps`` hands the end point to the reference's L-BFGS-B, which
+    returns at once from a stationary point and finishes the job where the iteration stalled next to a boundary.
+    Opt-in: ``REML(..., aireml=True)``; the default optimiser stays the reference's L-BFGS-B."""
     s2 = np.asarray(x0, dtype=float).copy()
     rng_state = np.random.get_state()
 
-    def evaluate(v):
-        np.random.set_state(rng_state)
-        nll, grad = bolt_gradient_estimation(v, cholesky_func, mats, covariates, y, reml, sim_num, False, take_exp=False)
-        if _is_hip(cholesky_func):
-            fac = cholesky_func._factor_state[id(cholesky_func.engine_for(mats))]
-        else:
-            fac = cholesky_func(matrices_weighted_sum(mats, v))
+    def information(fac):
         # P y and P A_k P y through the resident factor: 1 + K multi-column solves
         ViC = fac(covariates)
         G = la.cho_factor(covariates.T.dot(ViC))
@@ -464,7 +472,27 @@ def _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose, max
         APy = np.stack([m.dot(Py) for m in mats], axis=1)          # n x K
         PAPy = proj(APy)
         AI = 0.5 * APy.T.dot(PAPy)
-        return nll, grad, 0.5 * (AI + AI.T)
+        return 0.5 * (AI + AI.T)
+
+    exact_hip = _is_hip(cholesky_func) and bool(getattr(cholesky_func, 'exact_trace', False))
+
+    def evaluate(v):
+        np.random.set_state(rng_state)
+        if exact_hip:
+            # exact traces: the selected inverse overwrites the factor at the end of the evaluation, so the information
+            # matrix is computed INSIDE it, right before the inverse (_evaluate_hip's hook)
+            cholesky_func._before_traces = information
+            try:
+                nll, grad = bolt_gradient_estimation(v, cholesky_func, mats, covariates, y, reml, sim_num, False, take_exp=False)
+            finally:
+                cholesky_func._before_traces = None
+            return nll, grad, cholesky_func._hook_result
+        nll, grad = bolt_gradient_estimation(v, cholesky_func, mats, covariates, y, reml, sim_num, False, take_exp=False)
+        if _is_hip(cholesky_func):
+            fac = cholesky_func._factor_state[id(cholesky_func.engine_for(mats))]
+        else:
+            fac = cholesky_func(matrices_weighted_sum(mats, v))
+        return nll, grad, information(fac)
 
     def decrement(g, M):
         # Newton decrement g' AI^-1 g: the size of the gradient in the metric of the information matrix
@@ -483,12 +511,17 @@ def _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose, max
         t = 1.0
         accepted = False
         for halving in range(12):
-            cand = s2 + t * step
+            # a component the step would drive through zero is pulled to a tenth of its value instead (the other components
+            # still take their step: scaling the whole step by the most constrained component stalls the iteration next to a
+            # boundary the likelihood is flat along)
+            cand = np.maximum(s2 + t * step, 0.1 * s2)
             if np.all(cand > 1e-10 * s2.sum()):
                 nll_c, grad_c, AI_c = evaluate(cand)
                 # the estimator's gradient is not exactly the derivative of its likelihood value (exact log-det, estimated
                 # trace): a step counts as progress when either of them says so
-                if nll_c <= nll + 1e-12 * abs(nll) or decrement(grad_c, AI_c) < lam:
+                # (with exact traces the objective is deterministic and its gradient exact: only a likelihood that does not
+                # rise counts)
+                if nll_c <= nll + 1e-12 * abs(nll) or (not exact_hip and decrement(grad_c, AI_c) < lam):
                     accepted = True
                     break
             t *= 0.5

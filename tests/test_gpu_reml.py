@@ -240,6 +240,16 @@ def test_exact_trace_option_gives_the_analytic_gradient():
         # (REML appends the identity itself, SparseCholesky.py:178)
         res.append(M.REML(M.SparseCholesky(exact_trace=True), mats[:-1], C, y, verbose=False)["covariance coefficients"])
     assert rel_err(res[0], res[1]) < 1e-8  # (to rounding: the chain sweeps of the solves sum in arrival order)
+    # AI-REML on the exact-trace objective: the information matrix needs solves at the evaluation's sigma2, which the
+    # selected inverse consumes -- it is computed inside the evaluation, before the inverse.  Deterministic optimum = the
+    # L-BFGS-B one (both minimise the same smooth function).
+    # (the likelihood of this three-component problem is flat along the dominance component, so the two optimisers are
+    # compared through the objective they share, not through sigma2)
+    ai = M.REML(M.SparseCholesky(exact_trace=True), mats[:-1], C, y, verbose=False, aireml=True)["covariance coefficients"]
+    ys = y / y.std()
+    nll_ai = M.bolt_gradient_estimation(np.asarray(ai), chol, mats, C, ys, True, 100, False, take_exp=False)[0]
+    nll_lb = M.bolt_gradient_estimation(np.asarray(res[0]), chol, mats, C, ys, True, 100, False, take_exp=False)[0]
+    assert np.all(np.asarray(ai) > 0) and nll_ai < nll_lb + 1e-6 * abs(nll_lb)
 
 
 def test_selected_inverse_traces_at_100k_against_identity_solves():
