@@ -427,9 +427,14 @@ def estimate_var_comps(cholesky_func, mats, covariates, y, reml=True, sim_num=10
         if not (_is_hip(cholesky_func) and getattr(cholesky_func, 'exact_trace', False)):
             return s2
         # exact traces make the objective deterministic, so the end point can be CHECKED: the average-information step can
-        # stall next to a boundary the likelihood is flat along (a component pulled towards zero iteration after iteration);
-        # the reference's optimiser then finishes the job from where the iteration stopped -- it returns at once when that
-        # point already is stationary
+        # stall next to a boundary the likelihood is flat along (a component pulled towards zero iteration after iteration).
+        # Stationary = no component can still lower the likelihood by the reference's tolerance (ftol 1e-7, relative): raising a
+        # component with a negative derivative by its own size (at least 0.1 % of the total variance), or lowering one with a
+        # positive derivative to zero.  Only a point that fails this is handed to the reference's optimiser to finish.
+        nll_end, g_end = _ai_reml.last
+        reach = np.where(g_end < 0, np.maximum(s2, 1e-3 * s2.sum()), s2)
+        if np.max(np.abs(g_end) * reach) <= 1e-7 * max(abs(nll_end), 1.0):
+            return s2
         x0 = np.maximum(s2, 1e-8 * s2.sum())
     optObj = optimize.minimize(bolt_gradient_estimation, np.log(x0),
                                args=(cholesky_func, mats, covariates, y, reml, sim_num, verbose, True),
@@ -533,6 +538,7 @@ def _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose, max
         s2, nll, grad, AI = cand, nll_c, grad_c, AI_c
         if done:
             break
+    _ai_reml.last = (float(nll), np.asarray(grad, dtype=float).copy())  # (end point's objective and d nll / d sigma2)
     return s2
 
 
