@@ -1118,7 +1118,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     const char* eti = tune_env("SCILMM_TARGET_ITEMS");
     const char* emn = tune_env("SCILMM_MIN_ITEM");
     const char* edi = tune_env("SCILMM_DENSE_ITEMS");
-    const char* edf = getenv("SCILMM_DENSE_FILL");
+    const char* edf = tune_env("SCILMM_DENSE_FILL");
     const int64_t dense_fill = edf ? atoll(edf) : 256;  // workgroups per round the dense item counts are fitted to (0: no fitting)
     // k_dense_b items per launch (target): long tails want launches of several rounds of workgroups (300k: 384 / 512 / 768 /
     // 1024 / 2048 / 3072 = 1373 / 1369 / 1365 / 1357 / 1384 / 1407 ms, 1M: 1024 vs 2048 = 27.0 vs 27.35 s), the short chain of the
@@ -2237,8 +2237,9 @@ int run_rhs(scilmm_factor* fac, const double* dB, int32_t r, double* dX, int mod
     // the chain sweeps pick their own window width: 64 columns for long chains (every window streams the whole dense
     // tail once), 32 for short ones (twice the workgroups on the latency-bound chain)
     // (read per call: the parity tests force each width on small chains)
-    const int chain_wide_T = getenv("SCILMM_CHAIN_WIDE_T") ? atoi(getenv("SCILMM_CHAIN_WIDE_T")) : 256;
-    const int chain_full_T = getenv("SCILMM_CHAIN_FULL_T") ? atoi(getenv("SCILMM_CHAIN_FULL_T")) : 768;
+    const char* ecw = tune_env("SCILMM_CHAIN_WIDE_T");
+    const char* ecf = tune_env("SCILMM_CHAIN_FULL_T");
+    const int chain_wide_T = ecw ? atoi(ecw) : 256, chain_full_T = ecf ? atoi(ecf) : 768;
     auto launch_chain = [&](bool bwd) -> int {
       const bool wide = D->chain_T >= chain_wide_T;
       const bool full = D->chain_T >= chain_full_T && rp > 64;  // every column in one 112-wide window
