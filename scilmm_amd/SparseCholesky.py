@@ -56,7 +56,7 @@ class SparseCholesky(object):
     """
 
     def __init__(self, use_long=False, mode='supernodal', ordering_method='default', perm=None, fused=True,
-                 exact_trace=False, cache_dir=None, metrics=None):
+                 exact_trace=False, cache_dir=None, metrics=None, front_bits=64):
         _lib.lib()  # fail loudly when the HIP library is not built
         self._use_long = use_long
         self._mode = mode
@@ -73,6 +73,13 @@ class SparseCholesky(object):
         # metrics: path of a JSON-lines file (also SCILMM_METRICS) that receives one record per likelihood evaluation --
         # sigma2, nll, gradient, and the device timers of that evaluation
         self.metrics = metrics or os.environ.get("SCILMM_METRICS")
+        # front_bits=32 (opt-in; BASELINE configs[4]'s "fp64 factor with fp32 MFMA fronts"): the products of the dense-tail
+        # update run on the fp32 matrix pipe (scilmm_set_front_precision), everything else stays fp64 and the factor's solves
+        # are refined against the exact V (Factor.__call__); 1.4 - 1.5x the fp64 speed at the 300k / 1M configs.  A pattern
+        # whose dense tail is narrower than the engine's threshold keeps the fp64 path.
+        if front_bits not in (32, 64):
+            raise ValueError("front_bits must be 32 or 64")
+        self.front_bits = front_bits
         self._n_eval = 0
         self._cache = {}
 
@@ -117,6 +124,11 @@ class SparseCholesky(object):
         hit = self._cache.get(key)
         if hit is None:
             sym = Symbolic(mats, perm=self._perm, ordering=self._ordering(), cache=self.cache_dir)
+            if self.front_bits == 32:
+                try:
+                    sym.set_front_precision(32)
+                except _lib.ScilmmError:
+                    pass  # (no dense tail wide enough: this pattern is factorized in fp64 throughout)
             self._cache = {key: (sym, [m.data.copy() for m in mats])}
         else:
             sym, datas = hit

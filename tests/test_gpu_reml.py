@@ -252,6 +252,33 @@ def test_exact_trace_option_gives_the_analytic_gradient():
     assert np.all(np.asarray(ai) > 0) and nll_ai < nll_lb + 1e-6 * abs(nll_lb)
 
 
+def test_front_bits_option_of_the_drop_in_class(monkeypatch):
+    """SparseCholesky(front_bits=32): configs[4]'s arithmetic behind the reference's protocol -- same likelihood and gradient
+    as the fp64 engine to the accuracy of the fp32 products (solves are refined), with the same np.random stream; a pattern
+    without a dense tail silently stays fp64."""
+    M = importlib.import_module("scilmm_amd.SparseCholesky")
+    from scilmm_amd.harness import pedigree as H
+    monkeypatch.setenv("SCILMM_TUNING", "1")
+    monkeypatch.setenv("SCILMM_DENSE", "1")   # (the tail of a 10k pedigree is narrower than the automatic threshold)
+    mats, C, y = H.make_problem(10000, 0.01, seed=2)
+    mats = mats + [sp.identity(y.size, format="csr")]
+    x0 = np.log(np.array([0.4, 0.6]))
+    out = {}
+    for bits in (64, 32):
+        chol = M.SparseCholesky(front_bits=bits)
+        np.random.seed(3)
+        out[bits] = M.bolt_gradient_estimation(x0, chol, mats, C, y, True, 50, False)
+        assert getattr(chol.engine_for(mats), "front_bits", 64) == bits
+    assert abs(out[32][0] - out[64][0]) < 1e-8 * abs(out[64][0]) and rel_err(out[32][1], out[64][1]) < 1e-6
+    assert out[32][0] != out[64][0]           # (the fp32 products did run)
+    monkeypatch.delenv("SCILMM_DENSE")
+    small = M.SparseCholesky(front_bits=32)    # 2 x 2 blocks: no dense tail at all
+    f = small(sp.csr_matrix(np.array([[2.0, 0.5], [0.5, 1.0]])))
+    assert abs(f.logdet() - np.log(1.75)) < 1e-12
+    with pytest.raises(ValueError):
+        M.SparseCholesky(front_bits=16)
+
+
 def test_selected_inverse_traces_at_100k_against_identity_solves():
     """The selected inverse at BASELINE configs[1]'s size (100k individuals, K = 2; 1.7 TFLOP factor, 3.4 TFLOP inversion):
     tr(V^-1 A) and tr(V^-1) against the brute-force form (163 multi-column sweeps of the factor, 55 GB over PCIe) to 1e-8,
