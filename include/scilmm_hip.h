@@ -175,6 +175,8 @@ int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double
 int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r, double* out);
 /* Y = A_k X, row-major n x r (SparseCholesky.py:66,70,160,163) */
 int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, double* Y);
+/* the same with DEVICE pointers, asynchronous on the engine's stream (the residual of a refinement sweep without a host round trip) */
+int scilmm_spmm_dev(scilmm_symbolic* sym, int32_t k, const double* dX, int32_t r, double* dY);
 
 /* SURVEY section 8f rank 4 -- the exact tr(V^-1 A_k) of the gradient instead of the reference's Monte-Carlo estimate
  * (scilmm/SparseCholesky.py:49-52, :65).  scilmm_selected_inverse replaces, IN PLACE, every stored entry of the factor by

@@ -240,6 +240,25 @@ def _finish_on_device(torch, sym, fac, R, sig2g_array, covariates, y, reml, sim_
     torch.cuda.synchronize()
     fac.solve_dev(vp(dB.data_ptr()), c + 1 + sim_num, vp(dX.data_ptr()))
     sym.sync()
+    if getattr(sym, "front_bits", 64) == 32:
+        # fp32-product fronts: the factor carries a ~1e-7 backward error; the solve is refined against the exact
+        # V = sum_k sigma2_k A_k without leaving the device (what Factor.__call__ does through host buffers): each sweep
+        # = K SpMMs + one more solve on the resident factor and gains ~7 digits
+        r_all = c + 1 + sim_num
+        dY, dRes = torch.empty_like(dB), torch.empty_like(dB)
+        for _ in range(fac.REFINE_STEPS):
+            dRes.copy_(dB)
+            for k in range(len(sig2g_array)):
+                torch.cuda.synchronize()
+                sym.spmm_dev(k, vp(dX.data_ptr()), r_all, vp(dY.data_ptr()))
+                sym.sync()
+                dRes.sub_(dY, alpha=float(sig2g_array[k]))
+            torch.cuda.synchronize()
+            fac.solve_dev(vp(dRes.data_ptr()), r_all, vp(dY.data_ptr()))
+            sym.sync()
+            dX.add_(dY)
+        del dY, dRes
+        torch.cuda.synchronize()
     del dB
     Xh = dX[:, :c + 1].cpu().numpy()
     invV_C, invV_y0 = Xh[:, :c], Xh[:, c]
@@ -332,7 +351,7 @@ def _evaluate_hip(sig2g_array, cholesky_func, mats, covariates, y, reml, sim_num
         fac.refactorize_async(sig2g_array)
         R = np.random.randn(n, sim_num)
         fac.wait()
-    dev = None if exact or not cholesky_func.fused or getattr(sym, "front_bits", 64) == 32 else _device_buffers()
+    dev = None if exact or not cholesky_func.fused else _device_buffers()
     if dev is not None:
         return _finish_on_device(dev, sym, fac, R, sig2g_array, covariates, y, reml, sim_num)
     if not exact:

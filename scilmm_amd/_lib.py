@@ -61,7 +61,7 @@ SYMBOLS = [
     "scilmm_symbolic_create", "scilmm_symbolic_info", "scilmm_symbolic_get", "scilmm_symbolic_error",
     "scilmm_symbolic_free", "scilmm_symbolic_save", "scilmm_symbolic_load", "scilmm_symbolic_release_host_maps", "scilmm_values_upload", "scilmm_factorize", "scilmm_refactorize",
     "scilmm_refactorize_async", "scilmm_factor_wait", "scilmm_factor_free", "scilmm_logdet", "scilmm_solve", "scilmm_lmul", "scilmm_export_L",
-    "scilmm_quadforms", "scilmm_spmm", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
+    "scilmm_quadforms", "scilmm_spmm", "scilmm_spmm_dev", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free", "scilmm_ibd_values_device",
     "scilmm_values_download",
@@ -117,6 +117,7 @@ def lib():
     L.scilmm_export_L.argtypes = [vp, vp, vp, vp, P(i64)]
     L.scilmm_quadforms.argtypes = [vp, i32, vp, i32, vp]
     L.scilmm_spmm.argtypes = [vp, i32, vp, i32, vp]
+    L.scilmm_spmm_dev.argtypes = [vp, i32, vp, i32, vp]
     L.scilmm_solve_dev.argtypes = [vp, vp, i32, vp]
     L.scilmm_lmul_dev.argtypes = [vp, vp, i32, vp]
     L.scilmm_quadforms_dev.argtypes = [vp, i32, vp, i32, vp]

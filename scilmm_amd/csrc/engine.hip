@@ -2884,13 +2884,51 @@ int scilmm_spmm(scilmm_symbolic* sym, int32_t k, const double* X, int32_t r, dou
     if (S.is_diag[k])
       hipLaunchKernelGGL(k_spmm_diag, dim3(pb), dim3(256), 0, s, S.n, (const double*)D->vals[k], (const double*)D->W, rp, D->X);
     else
-      hipLaunchKernelGGL(k_spmm, dim3((unsigned)((S.nnz_pattern + 255) / 256)), dim3(256), 0, s, D->v, S.nnz_pattern,
-                         (const double*)D->vals[k], (const double*)D->W, rp, rc, D->X);
+    {
+      // (a wave per 256 pattern slots; lanes = right-hand-side columns)
+      const int64_t spw = 256, nwav = (S.nnz_pattern + spw - 1) / spw;
+      hipLaunchKernelGGL(k_spmm_w, dim3((unsigned)((nwav + 3) / 4)), dim3(256), 0, s, D->v, S.nnz_pattern, spw,
+                         (const double*)D->vals[k], (const double*)D->W, rp, D->X);
+    }
     hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, s, S.n, r, rp, cbeg, D->v.perm, (const double*)D->X, D->IO + cnt);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(Y, D->IO + cnt, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  return SCILMM_OK;
+}
+
+int scilmm_spmm_dev(scilmm_symbolic* sym, int32_t k, const double* dX, int32_t r, double* dY) {
+  // device-pointer form of scilmm_spmm (same [n][r] layout): asynchronous on the engine's stream, like the other _dev calls
+  if (!sym || !sym->S || !dX || !dY || r <= 0) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  const Symbolic& S = *sym->S;
+  if (k < 0 || k >= S.K || !D->have_vals[k]) return SCILMM_ERR_STATE;
+  st = ensure_work(sym, D);
+  if (st != SCILMM_OK) return st;
+  hipStream_t s = D->stream;
+  for (int32_t cbeg = 0; cbeg < r; cbeg += RPMAX) {
+    const int rc = std::min<int>(RPMAX, r - cbeg);
+    const int rp = rp_of(rc);
+    const int64_t tot = (int64_t)S.n * rp;
+    const unsigned pb = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_perm_in, dim3(pb), dim3(256), 0, s, S.n, r, rp, cbeg, D->v.perm, dX, D->W);
+    HIPCHK(hipMemsetAsync(D->X, 0, sizeof(double) * (size_t)tot, s));
+    if (S.is_diag[k])
+      hipLaunchKernelGGL(k_spmm_diag, dim3(pb), dim3(256), 0, s, S.n, (const double*)D->vals[k], (const double*)D->W, rp, D->X);
+    else
+    {
+      // (a wave per 256 pattern slots; lanes = right-hand-side columns)
+      const int64_t spw = 256, nwav = (S.nnz_pattern + spw - 1) / spw;
+      hipLaunchKernelGGL(k_spmm_w, dim3((unsigned)((nwav + 3) / 4)), dim3(256), 0, s, D->v, S.nnz_pattern, spw,
+                         (const double*)D->vals[k], (const double*)D->W, rp, D->X);
+    }
+    hipLaunchKernelGGL(k_perm_out, dim3(pb), dim3(256), 0, s, S.n, r, rp, cbeg, D->v.perm, (const double*)D->X, dY);
+  }
+  HIPCHK(hipGetLastError());
   return SCILMM_OK;
 }
 

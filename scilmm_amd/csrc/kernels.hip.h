@@ -2356,6 +2356,53 @@ __global__ void k_spmm(DevSym S, int64_t nnz, const double* __restrict__ vals, c
   }
 }
 
+// Y += A X with the lanes of a wave owning the right-hand-side columns (c, c + 64) -- k_quad's walk over a contiguous range of
+// pattern slots: per stored entry a_ij (i >= j) the row X[i] is read ONCE (both halves of the wave-wide row are coalesced), the
+// column's own sum Y[j] += a_ij X[i] is kept in registers and flushed when the column ends, and Y[i] += a_ij X[j] is one
+// coalesced wave-wide atomic add per half -- instead of k_spmm's thread per entry looping over the columns with scalar atomics
+// (300k config, 103 columns: 1.82 s -> see profiles).  Y must be zero (or hold the sum to add to) on entry.
+__global__ __launch_bounds__(256) void k_spmm_w(DevSym S, int64_t nnz, int64_t slots_per_wave, const double* __restrict__ vals,
+                                                const double* __restrict__ X, int32_t rp, double* __restrict__ Y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t e0 = wave * slots_per_wave;
+  const int64_t e1 = min(nnz, e0 + slots_per_wave);
+  if (e0 >= e1) return;
+  int32_t lo = 0, hi = S.n;
+  while (lo < hi) {
+    int32_t mid = (lo + hi) >> 1;
+    if (S.pat_colptr[mid + 1] <= e0) lo = mid + 1; else hi = mid;
+  }
+  int32_t j = lo;
+  int64_t cend = S.pat_colptr[j + 1];
+  const bool h0 = lane < rp, h1 = lane + 64 < rp;
+  double xj0 = h0 ? X[(int64_t)j * rp + lane] : 0.0, xj1 = h1 ? X[(int64_t)j * rp + lane + 64] : 0.0;
+  double a0 = 0.0, a1 = 0.0;
+  auto flush = [&]() {
+    if (h0 && a0 != 0.0) unsafeAtomicAdd(&Y[(int64_t)j * rp + lane], a0);
+    if (h1 && a1 != 0.0) unsafeAtomicAdd(&Y[(int64_t)j * rp + lane + 64], a1);
+    a0 = a1 = 0.0;
+  };
+  for (int64_t e = e0; e < e1; ++e) {
+    if (e >= cend) {
+      flush();
+      while (e >= cend) { ++j; cend = S.pat_colptr[j + 1]; }
+      xj0 = h0 ? X[(int64_t)j * rp + lane] : 0.0;
+      xj1 = h1 ? X[(int64_t)j * rp + lane + 64] : 0.0;
+    }
+    const int32_t i = S.pat_row[e];
+    const double a = vals[e];
+    if (a == 0.0) continue;
+    if (h0) a0 += a * X[(int64_t)i * rp + lane];
+    if (h1) a1 += a * X[(int64_t)i * rp + lane + 64];
+    if (i != j) {
+      if (h0) unsafeAtomicAdd(&Y[(int64_t)i * rp + lane], a * xj0);
+      if (h1) unsafeAtomicAdd(&Y[(int64_t)i * rp + lane + 64], a * xj1);
+    }
+  }
+  flush();
+}
+
 __global__ void k_spmm_diag(int32_t n, const double* __restrict__ dvals, const double* __restrict__ X, int32_t rp,
                             double* __restrict__ Y) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -184,6 +184,10 @@ class Symbolic(object):
     def sync(self):
         check(lib().scilmm_sync(self._h), self._h)
 
+    def spmm_dev(self, k, dX_ptr, r, dY_ptr):
+        """Y = A_k X with device pointers ([n][r] blocks), asynchronous on the engine's stream."""
+        check(lib().scilmm_spmm_dev(self._h, k, dX_ptr, r, dY_ptr), self._h)
+
     def quadforms_dev(self, k, dU_ptr, r, dout_ptr):
         check(lib().scilmm_quadforms_dev(self._h, k, dU_ptr, r, dout_ptr), self._h)
 

@@ -26,9 +26,9 @@ import bench  # noqa: E402
 SEED_FIT = 1
 
 
-def fit_hip(name, A, C, y, aireml=False, exact_trace=False):
+def fit_hip(name, A, C, y, aireml=False, exact_trace=False, front_bits=64):
     P = importlib.import_module("scilmm_amd.SparseCholesky")
-    chol = P.SparseCholesky(exact_trace=exact_trace)
+    chol = P.SparseCholesky(exact_trace=exact_trace, front_bits=front_bits)
     log, trace = [], []
     orig = P.bolt_gradient_estimation
 
@@ -50,6 +50,7 @@ def fit_hip(name, A, C, y, aireml=False, exact_trace=False):
     best = min(trace, key=lambda t: t[1])
     return {"engine": "HIP (scilmm_amd.REML, fused evaluation, device-resident n x 100 blocks)",
             "optimiser": "AI-REML" if aireml else "L-BFGS-B (the reference's)",
+            "front_bits": front_bits,
             "trace": "exact (selected inverse)" if exact_trace else "Monte-Carlo, 100 vectors (the reference's)",
             "fit_wall_s": tot, "evaluations": len(log), "first_evaluation_s": log[0],
             "median_later_evaluation_s": float(np.median(log[1:])) if len(log) > 1 else None,
@@ -92,6 +93,7 @@ def main():
     ap.add_argument("--cpu-port", action="store_true")
     ap.add_argument("--aireml", action="store_true", help="average-information iteration instead of L-BFGS-B")
     ap.add_argument("--exact-trace", action="store_true", help="tr(V^-1 A_k) from the selected inverse instead of the Monte-Carlo estimate")
+    ap.add_argument("--front-bits", type=int, default=64, choices=[32, 64], help="32: fp32-product fronts (BASELINE configs[4]'s arithmetic)")
     ap.add_argument("--compare", default=None)
     args = ap.parse_args()
     t0 = time.time()
@@ -101,7 +103,7 @@ def main():
            "seed_pedigree": 0, "seed_fit": SEED_FIT, "sim_num": 100,
            "reference": "REML(SparseCholesky(), [A], cov, y) -- /root/reference/scilmm/SparseCholesky.py:177-189"}
     print("problem: n=%d nnz=%d  (%.1f s)" % (n, A.nnz, rec["generate_s"]), flush=True)
-    rec.update(fit_cpu_port(args.workload, A, C, y) if args.cpu_port else fit_hip(args.workload, A, C, y, aireml=args.aireml, exact_trace=args.exact_trace))
+    rec.update(fit_cpu_port(args.workload, A, C, y) if args.cpu_port else fit_hip(args.workload, A, C, y, aireml=args.aireml, exact_trace=args.exact_trace, front_bits=args.front_bits))
     if args.compare:
         other = json.load(open(args.compare))
         rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
