@@ -1360,8 +1360,9 @@ __global__ __launch_bounds__(512, 1) void k_dense_f(DevSym S, int32_t dense_firs
 // Why k_dense_f is here: profiles/r3_mfma_f32_mix.txt (csrc/tools/mfma_f32_mix.hip) shows that the instruction mix is not
 // what holds the fp32-product kernels at half of the fp32 matrix rate (16 MFMAs + LDS fragments + a fold every 16 k-steps:
 // 135 of 155 TFLOP/s; a fold every 4 k-steps, k_dense32's period: 107), so removing conversions and folds bought nothing,
-// and the shorter chunks (a barrier per 32 k) cost 15 %.  What the three fp32 forms share is the fp64 OPERAND stream: a
-// 256 x 128 tile reads 32 flop per HBM byte, i.e. 2.7 TB/s at 83 TFLOP/s in 128-byte pieces -- the fp32 forms are bound by
+// and the shorter chunks (a barrier per 32 k) cost 15 %.  (The explanation that followed at the time -- the fp64 operand
+// stream -- was tested by k_dense_s / k_dense_t below and did not hold; the cause is the register pressure of the fp64 + fp32
+// sums of a 32 x 128 wave tile: DESIGN.md section 4.1, k_dense_h in csrc/kernels.hip.h.)
 // that stream, not by the matrix pipe.
 
 // ------------------------------------------------------------------------------------------------
@@ -1541,8 +1542,9 @@ __global__ __launch_bounds__(512, 1) void k_dense_s(DevSym S, int32_t dense_firs
 // the bytes per flop, no conversions at all) it reaches 86.3 TFLOP/s on the 1M-shaped launch against 83.2 (k_dense32) and 84.5
 // (k_dense_b's streams with fp32 products); with the A fragments fetched two sub-chunks ahead and a partial vmcnt wait at the
 // chunk barrier: 78 (more spills).  So neither the operand bytes nor the conversions nor the load latency explain the 0.55 of
-// the fp32 pipe all four forms share; what does is not found (the register-only / LDS-fed probe sustains 135 - 141 with the
-// same 16 MFMAs, fragment reads and fold per k-step).  Not worth + 50 % tail storage: the engine keeps k_dense32.
+// the fp32 pipe all four forms share.  What does was found two kernels later: this very kernel WITHOUT its fp64 accumulators
+// (-DSCILMM_DENSE_S_NOFOLD: 134 registers, no spills) runs at 118.5 -- the sums of a 32 x 128 wave tile do not fit two waves per SIMD.
+// k_dense_h (csrc/kernels.hip.h) keeps the shadow and halves the wave's columns.
 
 // ------------------------------------------------------------------------------------------------
 // k_dense_t (RETIRED before it shipped: 87 - 88 TFLOP/s alone, as the other two-waves-per-SIMD forms; the note at the end):
