@@ -128,7 +128,10 @@ class Symbolic(object):
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().scilmm_symbolic_free(h)
+            try:
+                lib().scilmm_symbolic_free(h)
+            except Exception:  # interpreter shutdown: the module's globals are already gone, the process frees everything
+                pass
             self._h = None
 
     def info(self):
@@ -246,7 +249,10 @@ class Factor(object):
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().scilmm_factor_free(h)
+            try:
+                lib().scilmm_factor_free(h)
+            except Exception:  # (interpreter shutdown, as above)
+                pass
             self._h = None
 
     def _rhs(self, fn, b):
