@@ -44,6 +44,10 @@ WORKLOADS = {
     "100k": (100000, 0.005),
     "300k": (300000, 0.003),     # scaling probe between configs[1] and configs[2] (2.0e9 nnz(L), 7.6e13 flops)
     "1m": (1000000, 0.001),      # configs[2]: n_eff 828k, nnz(L) 1.5e10 (123 GB), 1.6e15 flops -- see DESIGN.md
+    # configs[4]: 3M individuals, A + D + I, 8 ranks, fp32-product fronts (sparsity_factor 3e-4, 2.7e9 entries of A).
+    # Needs a multi-GPU node (~1.1 TB of factor: DESIGN.md section 7) and ~150 GB of host memory on rank 0; launched by hand:
+    #   python bench.py --gpus 8 --workload 3m --components A,D --front-bits 32 --budget-s 3000
+    "3m": (3000000, 0.0003),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_16x16x4_f32), 155 measured
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 matrix; MI355X_MICROARCH.md lists no fp64 figure
@@ -52,16 +56,16 @@ CPU_BASELINE_WORKLOAD = "100k"   # bounded sample for the host-cores baseline (a
 CPU_BASELINE_RESERVE_S = 75.0
 
 
-def build_problem(name, seed, components="A"):
+def build_problem(name, seed, components="A", parents=False):
     """components "A": (A, C, y); "A,D": ([A, D], C, y) with the dominance matrix D built on the device from A and the
-    parent table (BASELINE configs[4]'s second variance component; reference scilmm/Matrices/Dominance.py:12-43)."""
+    parent table (BASELINE configs[4]'s second variance component; reference scilmm/Matrices/Dominance.py:12-43).
+    parents=True: also the parent table of the cohort (after the unrelated-drop), from which the ranks of a multi-GPU run
+    build the VALUES of A and D in their own HBM."""
     from scilmm_amd.harness.pedigree import make_problem
     n, sf = WORKLOADS[name]
-    if components == "A":
-        mats, C, y = make_problem(n, sf, seed=seed)
-        return mats[0], C, y
-    mats, C, y = make_problem(n, sf, seed=seed, with_dominance="device")
-    return mats, C, y
+    out = make_problem(n, sf, seed=seed, with_dominance="device" if components != "A" else False, return_parents=parents)
+    mats = out[0]
+    return (mats[0] if components == "A" else mats,) + tuple(out[1:])
 
 
 def _effective_cpus():
@@ -152,6 +156,119 @@ def cpu_baseline(A, r, sample_name):
             "factor_s": t_fact, "solve_s": t_solve, "flops_per_s": cinfo.flops / t_fact, "logdet": cpu.logdet()}
 
 
+def plan_only(args):
+    """`--plan-only`: what ONE rank of `--gpus N` holds in HBM for a workload, from the REAL analysis of its pattern (VERDICT r3
+    item 1d).  Host part (no GPU): the pedigree's pattern only (no matrix value exists anywhere), the symbolic analysis, the
+    distribution rule read from the library (`scilmm_dist_layout`) -> exact byte counts of everything whose size the analysis
+    fixes.  Device part (when a GPU is present): the engine of rank `--plan-rank` is built WITHOUT peers -- its device plan
+    (work items, descriptors, cell lists), its share of the factor, the values of A (and D) computed in HBM -- no
+    factorization is run, and the HBM in use is read from the runtime.  Prints one JSON object; returns the exit status."""
+    import resource
+    from scilmm_amd.dist import tail_layout
+    from scilmm_amd.factor import Symbolic
+    from scilmm_amd.harness.pedigree import make_pattern_problem
+    world, rank = args.gpus, args.plan_rank
+    if world < 1 or not 0 <= rank < world:
+        sys.stderr.write("--plan-only: need --gpus >= 1 and 0 <= --plan-rank < --gpus\n")
+        return 2
+    k3 = args.components != "A"
+    n0, sf = WORKLOADS[args.workload]
+    t0 = time.time()
+    P, par, _ = make_pattern_problem(n0, sf, seed=int(os.environ.get("SCILMM_BENCH_SEED", "0")))
+    t_gen = time.time() - t0
+    n = P.shape[0]
+    mats_e = [P] + ([P] if k3 else []) + [sp.identity(n, format="csr")]
+    t0 = time.time()
+    have_gpu = False
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        pass
+    eng = None
+    if have_gpu and world > 1:
+        from scilmm_amd.dist import HipChainEngine
+        eng = HipChainEngine(mats_e, rank, world, None, "cuda:0")   # no peers: nothing collective is ever issued
+        sym = eng.sym
+    else:
+        sym = Symbolic(mats_e, upload=False)
+    t_sym = time.time() - t0
+    info = sym.info()
+    ns = info.nsuper
+    owner, loff, (first, Wg, G) = tail_layout(sym._h, ns, rank, world)
+    sn_loff = sym.get("sn_loff")
+    sn_rowptr = sym.get("sn_rowptr")
+    glob = np.append(sn_loff[:ns], info.nnzL_stored) if sn_loff.size == ns else sn_loff
+    sizes = np.diff(glob)
+    nT = ns - first
+    prelude = int(glob[first]) if first < ns else int(info.nnzL_stored)
+    slot = int(((sizes[first:] + 1) // 2 * 2).max()) if nT > 0 else 0
+    mine = [j for j in range(nT) if world > 1 and j % world == rank]
+    own = int(((sizes[first:][mine] + 1) // 2 * 2).sum()) if world > 1 else int(info.nnzL_stored) - prelude
+    ring = (min(G, nT) * slot) if world > 1 else 0
+    assert world == 1 or prelude + own + ring == int(loff[-1]), (prelude, own, ring, int(loff[-1]))
+    max_m = int(np.diff(sn_rowptr).max())
+    inv_doubles = int(sym.get("inv_off")[-1])
+    nnzp = int(info.nnz_pattern)
+    n_general = 2 if k3 else 1
+    r = 103
+    GB = 1e-9
+    comp = {
+        "factor_prelude_replicated": 8.0 * prelude,
+        "factor_own_tail_panels": 8.0 * own,
+        "factor_ring_slots": 8.0 * ring,
+        "factor_slack": 8.0 * (4 * max_m + 4 * 128),
+        "inverse_diagonal_blocks_replicated": 8.0 * inv_doubles,
+        "fp32_shadow_of_own_tail_and_ring": (4.0 * (own + ring + 16384)) if args.front_bits == 32 else 0.0,
+        "values_A_k_in_slot_order": 8.0 * (n_general * nnzp + n),
+        "assembly_maps_asm_dst_pat_row_colptr": 8.0 * nnzp + 4.0 * nnzp + 8.0 * 2 * n,
+        "sweep_work_buffers_W_X_ACC": 8.0 * (3 if world > 1 else 2) * n * 128,
+        "bench_io_B_X_and_refinement_blocks": 8.0 * n * r * (4 if args.front_bits == 32 else 2),
+    }
+    total_known = sum(comp.values())
+    out = {"plan_only": True, "workload": args.workload, "components": args.components, "front_bits": args.front_bits,
+           "world": world, "rank": rank, "n": n, "nnz_pattern_tril": nnzp, "nnzL": int(info.nnzL), "nnzL_stored": int(info.nnzL_stored),
+           "factor_flops": info.flops, "nsuper": ns, "tail_panels": nT, "tail_columns": int(n - sym.get("sn_start")[first]) if nT else 0,
+           "group_size": Wg, "ring_slots": min(G, nT) if world > 1 else 0, "largest_panel_MB": 8e-6 * slot,
+           "bytes_fixed_by_the_analysis_GB": {k: v * GB for k, v in comp.items()},
+           "sum_fixed_by_the_analysis_GB": total_known * GB,
+           "generate_s": t_gen, "analysis_s": t_sym,
+           "host_peak_rss_GB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024 * GB}
+    if have_gpu:
+        dev = torch.device("cuda", 0)
+        t0 = time.time()
+        if eng is None:
+            sym.upload_values()     # (the identity: the only matrix with host values; builds the device plan)
+        sym.ibd_values_from_pedigree(0, par)
+        if k3:
+            sym.dominance_values_from(1, 0, par)
+        torch.cuda.synchronize()
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        used = float(total_b - free_b)
+        # what the probe holds = everything above except the factor when world == 1 (allocated by the first factorization), the
+        # fp32 shadow (allocated by the first fp32-front factorization), the sweep buffers of a single-GPU handle (first solve)
+        # and the bench's blocks
+        held = dict(comp)
+        for k in ("fp32_shadow_of_own_tail_and_ring", "bench_io_B_X_and_refinement_blocks"):
+            held[k] = 0.0
+        if world == 1:
+            for k in ("factor_prelude_replicated", "factor_own_tail_panels", "factor_ring_slots", "factor_slack",
+                      "inverse_diagonal_blocks_replicated", "sweep_work_buffers_W_X_ACC"):
+                held[k] = 0.0
+        plan = used - sum(held.values())
+        out.update({"hbm_in_use_by_the_probe_GB": used * GB, "device_plan_and_runtime_GB": plan * GB,
+                    "hbm_per_rank_GB": (total_known + plan) * GB, "hbm_total_GB": total_b * GB,
+                    "device_plan_s": time.time() - t0,
+                    "note": "device_plan_and_runtime = HBM in use after building this rank's plan and values, minus the analysis-fixed "
+                            "terms the probe holds (includes the runtime's own ~1 GB and allocator rounding); hbm_per_rank = "
+                            "analysis-fixed terms + that"})
+    else:
+        out["note"] = ("no GPU here: the device plan (work items, descriptors, cell lists: 19 GB at 1M on one GPU, ~1/world of it plus 0.2 GB "
+                       "per rank when the tail is distributed) is not included -- run the same command on a GPU box for the measured figure")
+    print(json.dumps(out))
+    return 0
+
+
 def spawn_ranks(n):
     """Launcher half of `python bench.py --gpus N`: N children of this interpreter with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* set (127.0.0.1, a free port), the same command line; rank 0's stdout carries the JSON line.  The parent makes
@@ -211,8 +328,25 @@ def main():
     ap.add_argument("--front-bits", type=int, default=64, choices=[32, 64],
                     help="32: BASELINE configs[4]'s arithmetic (fp32 MFMA fronts, fp64 sums) -- NOT the headline metric; "
                          "the line then says so in `dtype` and `metric`")
+    ap.add_argument("--serialised", action="store_true",
+                    help="measurement mode: EVERY evaluation queues its look-ahead launches on one side stream (scilmm_set_profiling 2), so "
+                         "that a `rocprofv3 --kernel-trace --stats` of this command shows the dominant kernel's launch durations without "
+                         "overlap -- the figure `roofline.achieved` quotes; slower as a whole, same results; the line says so")
+    ap.add_argument("--no-engine-profiling", action="store_true",
+                    help="do not bracket the kernel classes with HIP events (for rocprofv3 --pmc passes: the counters serialise the "
+                         "dispatches anyway and ~20k extra event packets per factorization only load the intercepted queues); the "
+                         "line's roofline object is then null")
+    ap.add_argument("--dump-maps", default=None,
+                    help="write /proc/self/maps to this file right before the first evaluation (to symbolise a profiler-side crash offline)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="analyse the workload's pattern on the host and print, as one JSON object, what ONE rank of --gpus N holds in "
+                         "HBM (exact counts of the analysis and of the distribution rule; no GPU needed).  With a GPU present the "
+                         "device plan of rank --plan-rank is built as well (no peers, no factorization) and the HBM in use is measured.")
+    ap.add_argument("--plan-rank", type=int, default=0)
     args = ap.parse_args()
 
+    if args.plan_only:
+        raise SystemExit(plan_only(args))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "RANK" not in os.environ and args.gpus > 1:
@@ -262,9 +396,8 @@ def main():
     # One cohort for the whole job.  Rank 0 simulates it and hands it to the other ranks through /dev/shm (N
     # simultaneous simulations of a 1M pedigree would need N x 40 GB of host memory and N x the cores).
     seed = int(os.environ.get("SCILMM_BENCH_SEED", "0"))
-    comps = None  # extra variance-component matrices (K = 3: the dominance matrix), 1-GPU only
-    if args.components != "A" and world > 1:
-        raise SystemExit("--components A,D is a 1-GPU probe of BASELINE configs[4]'s model")
+    comps = None  # extra variance-component matrices on the host (K = 3: the dominance matrix; N > 1: on rank 0 only)
+    par = None    # N > 1: the cohort's parent table -- every rank builds the values of A (and D) in its own HBM from it
     if world == 1:
         A, C, y = build_problem(args.workload, seed=seed, components=args.components)
         if args.components != "A":
@@ -272,7 +405,7 @@ def main():
             A = A[0]
     else:
         # (hand-off directory: memory-backed /dev/shm when it has the room -- 26 GB at the 1M config -- else the temp directory)
-        need = {"1m": 40e9, "300k": 8e9}.get(args.workload, 2e9)
+        need = {"3m": 16e9, "1m": 6e9, "300k": 1e9}.get(args.workload, 0.5e9)  # (the pattern of A and the parent table: no values)
         import shutil
         import tempfile
         roots = [d for d in ("/dev/shm", os.environ.get("TMPDIR") or tempfile.gettempdir(), os.getcwd())
@@ -282,20 +415,27 @@ def main():
         roots = roots[:1]
         dist.broadcast_object_list(roots, src=0)  # (rank 0's choice: free space is a moving number)
         shm = "%s/scilmm_bench_%s_%s" % (roots[0], os.environ.get("MASTER_PORT", "0"), args.workload)
+        from scilmm_amd.factor import PatternCSR
         if rank == 0:
-            A, C, y = build_problem(args.workload, seed=seed)
+            # (rank 0 keeps the host matrices: it checks the residual of the last solve against them -- and with it the values
+            #  the ranks built on their devices)
+            A, C, y, par = build_problem(args.workload, seed=seed, components=args.components, parents=True)
+            if args.components != "A":
+                comps = A[1:]
+                A = A[0]
             np.save(shm + "_indptr.npy", A.indptr); np.save(shm + "_indices.npy", A.indices)
-            np.save(shm + "_data.npy", A.data); np.save(shm + "_C.npy", C); np.save(shm + "_y.npy", y)
+            np.save(shm + "_par.npy", par); np.save(shm + "_C.npy", C); np.save(shm + "_y.npy", y)
+            Apat = PatternCSR(A.indptr, A.indices, A.shape[0])
         dist.barrier()
         if rank != 0:
-            C, y = np.load(shm + "_C.npy"), np.load(shm + "_y.npy")
-            A = sp.csr_matrix((np.load(shm + "_data.npy"), np.load(shm + "_indices.npy"), np.load(shm + "_indptr.npy")),
-                              shape=(y.size, y.size))
+            C, y, par = np.load(shm + "_C.npy"), np.load(shm + "_y.npy"), np.load(shm + "_par.npy")
+            A = None
+            Apat = PatternCSR(np.load(shm + "_indptr.npy"), np.load(shm + "_indices.npy"), y.size)
         dist.barrier()
         if rank == 0:
-            for suffix in ("indptr", "indices", "data", "C", "y"):
+            for suffix in ("indptr", "indices", "par", "C", "y"):
                 os.remove(shm + "_%s.npy" % suffix)
-    n = A.shape[0]
+    n = y.size
     t_gen = time.time() - t0
     t0 = time.time()
     eng = None
@@ -310,21 +450,29 @@ def main():
         from scilmm_amd.dist import HipChainEngine
         # one analysis per NODE: rank 0 analyses the pattern and leaves its image in /dev/shm, the others load it
         cache = "%s/scilmm_bench_sym_%s" % (roots[0], os.environ.get("MASTER_PORT", "0"))
-        if rank == 0:
-            Symbolic([A, sp.identity(n, format="csr")], upload=False, cache=cache)
-        dist.barrier()
-        eng = HipChainEngine([A, sp.identity(n, format="csr")], rank, world, dist, dev, cache=cache)
+        # value-less patterns: A (and D on A's pattern, as the reference builds it) + the identity
+        mats_e = [Apat] + ([Apat] if args.components != "A" else []) + [sp.identity(n, format="csr")]
+        # (with a cache HipChainEngine lets rank 0 analyse and publish the image before the others load it)
+        eng = HipChainEngine(mats_e, rank, world, dist, dev, cache=cache)
         sym = eng.sym
+        # the values of A by the tabular recursion, those of D from A's resident slots: nothing but the pattern and the parent
+        # table reached this rank (scilmm_ibd_values_device, scilmm_dominance_values_device)
+        sym.ibd_values_from_pedigree(0, par)
+        if args.components != "A":
+            sym.dominance_values_from(1, 0, par)
         dist.barrier()
         if rank == 0:
             shutil.rmtree(cache, ignore_errors=True)
         # N processes of one node each hold the cohort and the analysis: drop what an evaluating rank no longer needs
         sym.release_host_maps()
-        if rank != 0:
-            A = None  # (only rank 0 checks the residual against the matrix)
+        del Apat, mats_e
     t_sym = time.time() - t0
     info = sym.info()
-    sym.set_profiling(True)
+    prof_mode = 0 if args.no_engine_profiling else (2 if args.serialised else 1)
+    if prof_mode:
+        sym.set_profiling(prof_mode)
+    if args.no_engine_profiling or args.serialised:
+        args.no_clean_profile = True
     if args.front_bits == 32:
         sym.set_front_precision(32)
 
@@ -334,13 +482,23 @@ def main():
     B_host = np.hstack([C, y[:, None], rng.standard_normal((n, s))])
     dB = torch.from_numpy(B_host).to(dev)   # every rank takes part in every column of the (collective) sweep
     dX = torch.empty_like(dB)
+    if args.front_bits == 32 and world == 1:
+        dY, dRes = torch.empty_like(dB), torch.empty_like(dB)
     torch.cuda.synchronize()
 
     state = {"fac": None}
     logdets = []
 
+    k3 = args.components != "A"
+    refine_steps = 2 if args.front_bits == 32 else 0
+    ev = None
+    if eng is not None and refine_steps:
+        from scilmm_amd.dist import DistributedEvaluator
+        ev = DistributedEvaluator(eng, [None] * (3 if k3 else 2), C, y, rank, world, dist, refine_steps=refine_steps)
+    refine_wall = [0.0]
+
     def sigma2_of(i):
-        if comps:  # K = 3: sigma2 = (additive, dominance, residual) around SURVEY's (0.3, 0.1, 0.6)
+        if k3:  # K = 3: sigma2 = (additive, dominance, residual) around SURVEY's (0.3, 0.1, 0.6)
             return [0.3 + 0.01 * (i % 3), 0.1, 0.6 - 0.01 * (i % 3)]
         return [0.4 + 0.01 * (i % 3), 0.6 - 0.01 * (i % 3)]
 
@@ -354,27 +512,39 @@ def main():
             state["fac"].refactorize(sigma2_of(i))
         fac = state["fac"]
         logdets.append(fac.logdet())
-        fac.solve_dev(ctypes.c_void_p(dB.data_ptr()), r, ctypes.c_void_p(dX.data_ptr()))
+        vp = ctypes.c_void_p
+        if ev is not None:
+            # fp32-product fronts on the multi-rank path: the collective sweep + the refinement sweeps against the exact V
+            # (column-split SpMMs + one all-reduce, one more collective sweep each: scilmm_amd/dist.py)
+            t_r = time.perf_counter()
+            dX.copy_(ev._refined_solve(np.asarray(sigma2_of(i)), dB, True))
+            torch.cuda.synchronize()
+            refine_wall[0] += time.perf_counter() - t_r
+            return
+        fac.solve_dev(vp(dB.data_ptr()), r, vp(dX.data_ptr()))
         sym.sync()  # (N > 1: every rank ends with all 103 solution columns, as the REML evaluation needs)
+        if refine_steps:
+            # fp32-product fronts: the step delivers the solve the REML evaluation uses -- refined on the device against the
+            # exact V = sum_k sigma2_k A_k (what scilmm_amd.SparseCholesky._finish_on_device does): K SpMMs + one more sweep each
+            t_r = time.perf_counter()
+            s2 = sigma2_of(i)
+            for _ in range(refine_steps):
+                dRes.copy_(dB)
+                for k in range(len(s2)):
+                    torch.cuda.synchronize()
+                    sym.spmm_dev(k, vp(dX.data_ptr()), r, vp(dY.data_ptr()))
+                    sym.sync()
+                    dRes.sub_(dY, alpha=float(s2[k]))
+                torch.cuda.synchronize()
+                fac.solve_dev(vp(dRes.data_ptr()), r, vp(dY.data_ptr()))
+                sym.sync()
+                dX.add_(dY)
+            torch.cuda.synchronize()
+            refine_wall[0] += time.perf_counter() - t_r
 
-    if os.environ.get("SCILMM_PMC_GUARD") == "1" and rank == 0:
-        # Diagnostic for the rocprofv3 --pmc abort at the 1M workload: the tool's frames fault in a
-        # libc copy at the first page BEHIND a mapping that follows libscilmm_hip.so.  Print the neighbourhood and map
-        # readable zero pages into every hole right behind the library's mappings (never over an existing mapping), so
-        # that such an over-read lands on zeros instead of on nothing.
-        libc = ctypes.CDLL(None, use_errno=True)
-        libc.mmap.restype = ctypes.c_void_p
-        libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
-        maps = [ln.split() for ln in open("/proc/self/maps")]
-        spans = [(int(m[0].split("-")[0], 16), int(m[0].split("-")[1], 16), m[-1] if len(m) > 5 else "") for m in maps]
-        for i, (a, b, name) in enumerate(spans):
-            if "libscilmm_hip" in name or (i > 0 and "libscilmm_hip" in spans[i - 1][2] and not name):
-                nxt = spans[i + 1][0] if i + 1 < len(spans) else b
-                sys.stderr.write("[maps] %x-%x %s (hole behind it: %d KiB)\n" % (a, b, name, (nxt - b) // 1024))
-                hole = min(nxt - b, 64 << 20)
-                if hole > 0:
-                    got = libc.mmap(ctypes.c_void_p(b), hole, 1, 0x2 | 0x20 | 0x100000, -1, 0)  # PROT_READ, PRIVATE|ANON|FIXED_NOREPLACE
-                    sys.stderr.write("[maps]   guard pages at %x: %s\n" % (b, "ok" if got == b else "not placed"))
+    if args.dump_maps and rank == 0:
+        with open("/proc/self/maps") as fi, open(args.dump_maps, "w") as fo:
+            fo.write(fi.read())
     t0 = time.time()
     step(0)  # the plan-building evaluation always runs before the timed region: it is the first warm-up step
     t_first = time.time() - t0
@@ -399,6 +569,7 @@ def main():
     t0 = time.perf_counter()
     prof = {"dense_ms": 0.0, "n_dense_launches": 0, "update_union_ms": 0.0, "update_ms": 0.0, "potrf_ms": 0.0, "trsm_ms": 0.0, "reduce_cells_ms": 0.0, "assemble_ms": 0.0, "factor_ms": 0.0,
             "solve_fwd_ms": 0.0, "solve_bwd_ms": 0.0, "n_update_launches": 0, "n_launches": 0}
+    refine_wall[0] = 0.0
     for i in range(steps):
         step(i)
         t = sym.timing()
@@ -412,6 +583,12 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    hbm_used = float(total_b - free_b)   # this rank's device: factor share, plan, values, work buffers, allocator caches
+    if world > 1:
+        hmax = torch.tensor([hbm_used], dtype=torch.float64, device=rdev)
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        hbm_used = float(hmax[0])
     nnzL_total = float(info.nnzL)  # ONE cohort, whatever the number of ranks
     logdet_total = logdets[-1]
 
@@ -423,7 +600,7 @@ def main():
         sym.set_profiling(2)
         step(steps - 1)  # (same sigma2 as the last timed step: the residual check below is of this solve)
         clean = sym.timing()
-        sym.set_profiling(1)
+        sym.set_profiling(prof_mode)
         logdets.pop()
     # residual check of the last solve (outside the timed region)
     fac = state["fac"]
@@ -477,7 +654,9 @@ def main():
             flops_k, n_k, ms_k = info.update_flops * K, n_upd, prof["update_ms"]
         ach_overlapped = flops_k / max(ms_k / 1e3, 1e-12) / 1e12
         ach = ach_overlapped
-        clean_note = "launch durations of the timed steps (two launches overlap at any time)"
+        clean_note = ("launch durations of the timed steps (two launches overlap at any time)" if not args.serialised else
+                      "the timed steps themselves, run with the look-ahead launches serialised on one stream (--serialised): launch "
+                      "durations do not overlap each other; rocprofv3 --kernel-trace --stats of this command shows the same average")
         if clean is not None:
             # the same kernel class in the serialised evaluation: its algorithmic flops over ITS summed launch durations
             c_ms = clean["dense_ms"] if dense_on else clean["update_ms"]
@@ -500,7 +679,7 @@ def main():
         if traffic is None and traffic_per_flop is not None:
             traffic = traffic_per_flop * flops_k / max(n_k, 1)
         out = {
-            "metric": ("REML factorize+solve nnz(L)/s (simulated pedigree, fp64)" if not comps else
+            "metric": ("REML factorize+solve nnz(L)/s (simulated pedigree, fp64)" if not k3 else
                        "REML factorize+solve nnz(L)/s (simulated pedigree, K=3 A+D+I, fp64: configs[4]'s model, NOT the headline)") if args.front_bits == 64 else
                       "REML factorize+solve nnz(L)/s (simulated pedigree, fp64 factor with fp32 MFMA fronts: configs[4] arithmetic, NOT the fp64 headline)",
             "value": nnzL_total * K / elapsed,
@@ -512,8 +691,11 @@ def main():
             "dtype": "f64" if args.front_bits == 64 else "f64 sums / f32 MFMA products in the dense tail", "data": "synthetic",
             "config": {"workload": "simulated pedigree %s (n=%d after unrelated-drop, sparsity_factor %g), %s, "
                                    "r=%d fused right-hand sides" % (args.workload, n, WORKLOADS[args.workload][1],
-                                                                    "K=3 (A + D + I; D built on the device)" if comps else "K=2 (A + I)", r),
-                       "baseline_config": {"10k": "configs[0]", "100k": "configs[1]", "1m": "configs[2]"}.get(args.workload, "probe"),
+                                                                    "K=3 (A + D + I; D built on the device)" if k3 else "K=2 (A + I)", r),
+                       "baseline_config": ("configs[4]" if (args.workload == "3m" and k3 and args.front_bits == 32 and world == 8) else
+                                           "configs[3]" if (args.workload == "1m" and not k3 and args.front_bits == 64 and world == 8) else
+                                           {"10k": "configs[0]", "100k": "configs[1]", "1m": "configs[2]"}.get(args.workload, "probe")
+                                           if (world == 1 and not k3 and args.front_bits == 64) else "probe"),
                        "step_budget": "; ".join(reasons) if reasons else "requested counts run unchanged",
                        "n": n, "nnz_tril_A": int((A.nnz + n) // 2), "nnzL": int(info.nnzL),
                        "nnzL_stored": int(info.nnzL_stored), "factor_flops": info.flops, "nsuper": info.nsuper,
@@ -522,6 +704,11 @@ def main():
                                       "with rank-local storage (panel broadcast over RCCL into a ring, batched group updates), "
                                       "prelude replicated, collective sweeps" % world,
                        "local_factor_GB": (8e-9 * eng.local_factor_doubles) if eng is not None else 8e-9 * info.nnzL_stored,
+                       "hbm_in_use_GB_max_over_ranks": hbm_used / 1e9,
+                       "values": "A by scilmm_ibd_values_device%s in every rank's HBM from the pattern + parent table" % (
+                           ", D by scilmm_dominance_values_device" if k3 else "") if eng is not None else "uploaded from the host",
+                       "refinement": ("%d sweeps per step against the exact V on the device (fp32-product fronts), %.3f s per step, inside "
+                                      "the timed step" % (refine_steps, refine_wall[0] / K)) if refine_steps else "none (fp64 factor)",
                        "seconds_per_step": elapsed / K,
                        "factorize_ms": prof["factor_ms"] / K, "assemble_ms": prof["assemble_ms"] / K,
                        "solve_ms": (prof["solve_fwd_ms"] + prof["solve_bwd_ms"]) / K,
@@ -572,6 +759,10 @@ def main():
                                        "kind": "port", "sample": "failed: %r" % (e,)}
         else:
             out["cpu_baseline"] = None
+        if args.no_engine_profiling:
+            out["roofline"] = None   # (no HIP-event brackets were taken: nothing to quote)
+        if args.serialised:
+            out["config"]["mode"] = "--serialised: a measurement mode (look-ahead launches on one stream), slower than the default schedule"
         out["config"]["process_wall_s"] = time.time() - T_PROCESS_START
         print(json.dumps(out))
     if world > 1:

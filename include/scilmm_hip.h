@@ -267,6 +267,14 @@ void scilmm_ibd_free(scilmm_ibd* h);
  * (the row order of the matrices given to scilmm_symbolic_create); the analysed pattern must contain every pair with a
  * common ancestor (scilmm_ibd_build's pattern does).  Exact: the values are dyadic rationals. */
 int scilmm_ibd_values_device(scilmm_symbolic* sym, int32_t k, int32_t n, const int32_t* parents);
+/* The VALUES of the dominance relationship matrix computed on the device from the IBD values of matrix k_src already
+ * resident in HBM, straight into the value slots of matrix k_dst (replaces reference scilmm/Matrices/Dominance.py:12-43
+ * `dominance(rel, ibd)` and the upload of its result; scilmm_dominance / scilmm_dominance_dev are the CSR-layout forms):
+ *   D[a,b] = 1/4 (A[f_a,f_b] A[m_a,m_b] + A[f_a,m_b] A[m_a,f_b]) for a != b, 1 on the diagonal, on every slot of the
+ * analysed pattern (matrix k_dst is given to scilmm_symbolic_create with matrix k_src's pattern, as the reference builds
+ * it).  Bit-identical to the reference's NumPy arithmetic.  With scilmm_ibd_values_device, BASELINE configs[4]'s two
+ * variance components are built where they are used: only the pattern and the parent table reach a rank. */
+int scilmm_dominance_values_device(scilmm_symbolic* sym, int32_t k_dst, int32_t k_src, int32_t n, const int32_t* parents);
 /* Matrix k's device-resident values in PATTERN-SLOT order (scilmm_symbolic_get "pat_colptr" / "pat_row": permuted CSC of
  * the lower triangle, diagonal first; n values for a diagonal-only matrix) -- for tests and diagnostics. */
 int scilmm_values_download(scilmm_symbolic* sym, int32_t k, double* slots_out);

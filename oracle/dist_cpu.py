@@ -209,3 +209,7 @@ class CpuChainEngine(object):
 
     def quadforms(self, k, Q):
         return O.quadforms(self.mats[k], Q)
+
+    def spmm(self, k, X):
+        """A_k X (the residual of DistributedEvaluator's refinement sweeps)."""
+        return self.mats[k] @ np.asarray(X)

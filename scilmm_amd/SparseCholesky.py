@@ -751,10 +751,13 @@ def read_relationship_matrix(path):
     """``mmread(path).tocsr()`` of the reference (SparseCholesky.py:399) -- natively parsed; ``.npz`` also accepted."""
     if str(path).endswith('.npz'):
         return sparse.load_npz(path).tocsr()
-    try:
-        return _lib.read_matrix_market(path)
-    except _lib.ScilmmError:
-        return mmread(path).tocsr()  # array-format / complex files: SciPy's general reader
+    with open(path, 'rb') as fh:
+        banner = fh.readline(1024).decode('latin-1').lower()
+    if banner.startswith('%%matrixmarket') and any(w in banner.split() for w in ('array', 'complex', 'hermitian')):
+        # the two layouts the native parser does not take (dense array format, complex values) go to SciPy's general reader --
+        # decided from the banner, never as a reaction to a parse error: a malformed coordinate file raises (VERDICT r3 #15)
+        return sparse.csr_matrix(mmread(path))
+    return _lib.read_matrix_market(path)
 
 
 def run_estimates_from_paths(A, phe, cov, reml=False, ignore_indices=False):

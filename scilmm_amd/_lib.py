@@ -64,7 +64,7 @@ SYMBOLS = [
     "scilmm_quadforms", "scilmm_spmm", "scilmm_spmm_dev", "scilmm_solve_dev", "scilmm_lmul_dev", "scilmm_quadforms_dev",
     "scilmm_sync", "scilmm_last_timing", "scilmm_set_profiling", "scilmm_version",
     "scilmm_ibd_build", "scilmm_ibd_sizes", "scilmm_ibd_export", "scilmm_ibd_free", "scilmm_ibd_values_device",
-    "scilmm_values_download",
+    "scilmm_dominance_values_device", "scilmm_values_download",
     "scilmm_order", "scilmm_fill_count",
     "scilmm_dist_init", "scilmm_dist_work_size", "scilmm_dist_set_work", "scilmm_dist_layout", "scilmm_factor_sizes", "scilmm_factor_create_external", "scilmm_he_moments", "scilmm_set_front_precision",
     "scilmm_selected_inverse", "scilmm_inverse_traces",
@@ -131,6 +131,7 @@ def lib():
     L.scilmm_ibd_free.argtypes = [vp]
     L.scilmm_ibd_values_device.argtypes = [vp, i32, i32, vp]
     L.scilmm_values_download.argtypes = [vp, i32, vp]
+    L.scilmm_dominance_values_device.argtypes = [vp, i32, i32, i32, vp]
     L.scilmm_ibd_free.restype = None
     L.scilmm_mm_read.argtypes = [C.c_char_p, P(vp), P(i32), P(i32), P(i64)]
     L.scilmm_mm_export.argtypes = [vp, vp, vp, vp]

@@ -3068,6 +3068,47 @@ int scilmm_ibd_values_device(scilmm_symbolic* sym, int32_t k, int32_t n, const i
   return SCILMM_OK;
 }
 
+int scilmm_dominance_values_device(scilmm_symbolic* sym, int32_t k_dst, int32_t k_src, int32_t n, const int32_t* parents) {
+  if (!sym || !sym->S || !parents) return SCILMM_ERR_ARG;
+  DevGuard guard(sym);
+  const Symbolic& S = *sym->S;
+  if (k_dst < 0 || k_dst >= S.K || k_src < 0 || k_src >= S.K || k_dst == k_src || n != S.n || S.is_diag[k_dst] || S.is_diag[k_src])
+    return SCILMM_ERR_ARG;
+  for (int64_t t = 0; t < 2 * (int64_t)n; ++t)
+    if (parents[t] >= n) {
+      sym->err = "scilmm_dominance_values_device: parent index out of range";
+      return SCILMM_ERR_ARG;
+    }
+  Dev* D;
+  int st = ensure_device(sym, &D);
+  if (st != SCILMM_OK) return st;
+  if (!D->have_vals[k_src]) {
+    sym->err = "scilmm_dominance_values_device: the values of the source matrix are not resident";
+    return SCILMM_ERR_STATE;
+  }
+  hipStream_t s0 = D->stream;
+  int32_t *d_par = nullptr, *d_iperm = nullptr;
+  struct Cleanup {
+    int32_t*& a;
+    int32_t*& b;
+    ~Cleanup() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+  } cleanup{d_par, d_iperm};
+  HIPCHK(hipMalloc((void**)&d_par, sizeof(int32_t) * 2 * (size_t)std::max(n, 1)));
+  HIPCHK(hipMalloc((void**)&d_iperm, sizeof(int32_t) * (size_t)std::max(n, 1)));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(d_par, parents, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyHostToDevice, s0));
+    HIPCHK(hipMemcpyAsync(d_iperm, S.iperm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s0));
+  }
+  if (!D->vals[k_dst]) HIPCHK(hipMalloc((void**)&D->vals[k_dst], std::max<size_t>((size_t)S.nnz_pattern, 1) * sizeof(double)));
+  if (S.nnz_pattern > 0)
+    hipLaunchKernelGGL(k_dom_slots, dim3(4096), dim3(256), 0, s0, n, D->v.pat_colptr, D->v.pat_row, D->v.perm, (const int32_t*)d_iperm,
+                       (const int32_t*)d_par, (const double*)D->vals[k_src], D->vals[k_dst]);
+  HIPCHK(hipStreamSynchronize(s0));
+  HIPCHK(hipGetLastError());
+  D->have_vals[k_dst] = 1;
+  return SCILMM_OK;
+}
+
 int scilmm_values_download(scilmm_symbolic* sym, int32_t k, double* slots_out) {
   if (!sym || !sym->S || !sym->device || !slots_out) return SCILMM_ERR_ARG;
   DevGuard guard(sym);
@@ -3307,11 +3348,12 @@ int scilmm_set_front_precision(scilmm_symbolic* sym, int32_t bits) {
   Dev* D;
   int st = ensure_device(sym, &D);
   if (st != SCILMM_OK) return st;
-  D->front_bits = bits;
   if (bits == 32 && !D->dense_on) {
+    // (the handle keeps the precision it had: a refused request must not leave a half-set mode behind)
     sym->err = "fp32 fronts need the dense-tail path (tail narrower than 8192 columns: set SCILMM_TUNING=1 SCILMM_DENSE=1)";
     return SCILMM_ERR_STATE;
   }
+  D->front_bits = bits;
   return SCILMM_OK;
 }
 

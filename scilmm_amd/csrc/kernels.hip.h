@@ -2974,4 +2974,32 @@ __global__ __launch_bounds__(256) void k_ibd_pass(int64_t cnt, const uint32_t* _
   vals[e] = v;
 }
 
+// Dominance relationship values ON THE DEVICE in the engine's slot order, from the IBD values already resident in HBM
+// (reference scilmm/Matrices/Dominance.py:12-43; the CSR-layout form is csrc/dominance.hip):
+//     D[a, b] = 1/4 (A[f_a, f_b] A[m_a, m_b] + A[f_a, m_b] A[m_a, f_b]),  D[a, a] = 1,  unknown parent: 0,
+// one wave per pattern column (permuted labels), the four look-ups by bisection in the permuted pattern columns like
+// k_ibd_pass.  Products and the sum rounded one by one (no fma contraction) in the reference's order: the values equal
+// NumPy's bit for bit, and (a, b) / (b, a) give the same bits, so the lower-triangle slot holds either.
+__global__ __launch_bounds__(256) void k_dom_slots(int32_t n, const int64_t* __restrict__ colptr, const int32_t* __restrict__ prow,
+                                                   const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm,
+                                                   const int32_t* __restrict__ par, const double* __restrict__ A, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = wave; c < n; c += nw) {
+    const int32_t a = perm[c];
+    const int32_t fa = par[2 * (int64_t)a], ma = par[2 * (int64_t)a + 1];
+    for (int64_t e = colptr[c] + lane; e < colptr[c + 1]; e += 64) {
+      const int32_t b = perm[prow[e]];
+      double v = 1.0;
+      if (a != b) {
+        const int32_t fb = par[2 * (int64_t)b], mb = par[2 * (int64_t)b + 1];
+        const double p1 = __dmul_rn(ibd_look(fa, fb, colptr, prow, iperm, A), ibd_look(ma, mb, colptr, prow, iperm, A));
+        const double p2 = __dmul_rn(ibd_look(fa, mb, colptr, prow, iperm, A), ibd_look(ma, fb, colptr, prow, iperm, A));
+        v = __dmul_rn(0.25, __dadd_rn(p1, p2));
+      }
+      out[e] = v;
+    }
+  }
+}
+
 }  // namespace scilmm

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <unistd.h>
 
 namespace scilmm {
 
@@ -1255,16 +1256,44 @@ void build_tile_combos(Symbolic* S, const uint8_t* keep_front, bool skip_dense, 
 // Plain binary: a header, then every member of Symbolic in the order of the list below -- which is the single place that
 // names them, for writing and for reading.  The tile combos (built lazily per rank) are not part of the image.
 namespace {
-constexpr uint64_t kImageMagic = 0x53434c4d53594d33ull;  // "SCLMSYM3"
+constexpr uint64_t kImageMagic = 0x53434c4d53594d34ull;  // "SCLMSYM4" (4: length + checksum trailer)
 
+// Every byte that passes through pod() / vec() is counted and folded into a 64-bit checksum (four interleaved
+// multiply-xorshift lanes over 8-byte words: memory speed); the writer appends (bytes, checksum) as a trailer and the
+// reader refuses an image whose trailer does not match what it read -- a truncated or torn file (two writers on one
+// name, a copy cut short) is then a cache miss, never a wrong analysis.
 struct ImageIO {
   FILE* fp;
   bool write;
   bool ok = true;
+  uint64_t bytes = 0;
+  uint64_t lane[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+  void fold(const void* p, size_t nbytes) {
+    const unsigned char* b = (const unsigned char*)p;
+    size_t i = 0;
+    uint64_t l0 = lane[0], l1 = lane[1], l2 = lane[2], l3 = lane[3];
+    for (; i + 32 <= nbytes; i += 32) {
+      uint64_t w[4];
+      std::memcpy(w, b + i, 32);
+      l0 = (l0 ^ w[0]) * 0x9e3779b97f4a7c15ull; l0 ^= l0 >> 29;
+      l1 = (l1 ^ w[1]) * 0xc2b2ae3d27d4eb4full; l1 ^= l1 >> 31;
+      l2 = (l2 ^ w[2]) * 0x165667b19e3779f9ull; l2 ^= l2 >> 30;
+      l3 = (l3 ^ w[3]) * 0x27d4eb2f165667c5ull; l3 ^= l3 >> 28;
+    }
+    for (; i < nbytes; ++i) { l0 = (l0 ^ b[i]) * 0x100000001b3ull; l0 ^= l0 >> 32; }
+    lane[0] = l0; lane[1] = l1; lane[2] = l2; lane[3] = l3;
+    bytes += nbytes;
+  }
+  uint64_t checksum() const {
+    uint64_t h = bytes;
+    for (int q = 0; q < 4; ++q) { h = (h ^ lane[q]) * 0x9e3779b97f4a7c15ull; h ^= h >> 32; }
+    return h;
+  }
   template <typename T>
   void pod(T& v) {
     if (!ok) return;
     ok = write ? fwrite(&v, sizeof(T), 1, fp) == 1 : fread(&v, sizeof(T), 1, fp) == 1;
+    if (ok) fold(&v, sizeof(T));
   }
   template <typename T>
   void vec(std::vector<T>& v) {
@@ -1276,6 +1305,7 @@ struct ImageIO {
       v.resize((size_t)cnt);
     }
     if (cnt) ok = write ? fwrite(v.data(), sizeof(T), (size_t)cnt, fp) == cnt : fread(v.data(), sizeof(T), (size_t)cnt, fp) == cnt;
+    if (ok && cnt) fold(v.data(), sizeof(T) * (size_t)cnt);
   }
   template <typename T>
   void vecvec(std::vector<std::vector<T>>& v) {
@@ -1304,16 +1334,24 @@ void image_fields(ImageIO& io, Symbolic& S) {
 }  // namespace
 
 bool symbolic_save(const Symbolic& S, const char* path, uint64_t key) {
-  const std::string tmp = std::string(path) + ".tmp";
-  FILE* fp = fopen(tmp.c_str(), "wb");
+  // a name of this writer's own (pid + clock + address entropy): ranks that miss the cache at the same time each write a
+  // complete image and the LAST rename wins -- none truncates a file another one is still writing
+  char suffix[96];
+  const uint64_t salt = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)&S;
+  snprintf(suffix, sizeof suffix, ".tmp.%ld.%016llx", (long)getpid(), (unsigned long long)salt);
+  const std::string tmp = std::string(path) + suffix;
+  FILE* fp = fopen(tmp.c_str(), "wbx");  // (x: fail rather than share a name)
   if (!fp) return false;
   ImageIO io{fp, true};
   uint64_t magic = kImageMagic, k = key, nb = (uint64_t)SCILMM_NB;
   io.pod(magic); io.pod(k); io.pod(nb);
   image_fields(io, const_cast<Symbolic&>(S));
-  const bool ok = io.ok && fclose(fp) == 0;
+  uint64_t trailer[2] = {io.bytes, io.checksum()};
+  const bool wrote = io.ok && fwrite(trailer, sizeof(uint64_t), 2, fp) == 2;
+  const bool ok = (fclose(fp) == 0) && wrote;
   if (!ok) { remove(tmp.c_str()); return false; }
-  return rename(tmp.c_str(), path) == 0;  // readers never see a half-written image
+  if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return false; }  // readers never see a half-written image
+  return true;
 }
 
 Symbolic* symbolic_load(const char* path, uint64_t key) {
@@ -1325,11 +1363,34 @@ Symbolic* symbolic_load(const char* path, uint64_t key) {
   if (!io.ok || magic != kImageMagic || k != key || nb != (uint64_t)SCILMM_NB) { fclose(fp); return nullptr; }
   Symbolic* S = new Symbolic();
   image_fields(io, *S);
+  uint64_t trailer[2] = {0, 0};
+  const bool trailer_ok = io.ok && fread(trailer, sizeof(uint64_t), 2, fp) == 2 && trailer[0] == io.bytes && trailer[1] == io.checksum() &&
+                          fgetc(fp) == EOF;
   fclose(fp);
-  // structural sanity: sizes must agree with the header fields
-  const bool sane = io.ok && S->n >= 0 && (int64_t)S->perm.size() == S->n && (int64_t)S->sn_start.size() == (int64_t)S->nsuper + 1 &&
-                    (int64_t)S->sn_loff.size() >= S->nsuper && (int64_t)S->asm_dst.size() == S->nnz_pattern &&
-                    (int64_t)S->val_slot.size() == S->K && (int64_t)S->level_ptr.size() == (int64_t)S->nlevels + 1;
+  // structural sanity: sizes must agree with the header fields, indices must stay inside what they index
+  bool sane = trailer_ok && S->n >= 0 && S->nsuper >= 0 && (int64_t)S->perm.size() == S->n && (int64_t)S->iperm.size() == S->n &&
+              (int64_t)S->sn_start.size() == (int64_t)S->nsuper + 1 && (int64_t)S->sn_rowptr.size() == (int64_t)S->nsuper + 1 &&
+              (int64_t)S->sn_loff.size() >= S->nsuper && (int64_t)S->asm_dst.size() == S->nnz_pattern &&
+              (int64_t)S->diag_dst.size() == S->n && (int64_t)S->pat_colptr.size() == (int64_t)S->n + 1 &&
+              (int64_t)S->val_slot.size() == S->K && (int64_t)S->val_src.size() == S->K &&
+              (int64_t)S->level_ptr.size() == (int64_t)S->nlevels + 1;
+  if (sane) {
+    const int64_t n = S->n, nst = S->nnzL_stored;
+    bool ok_perm = true, ok_rows = true, ok_asm = true;
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t p = S->perm[(size_t)i];
+      if (p < 0 || p >= n || S->iperm[(size_t)p] != (int32_t)i) { ok_perm = false; break; }
+    }
+    const int64_t nrows = (int64_t)S->sn_rows.size();
+    if (nrows != S->sn_rowptr[(size_t)S->nsuper]) ok_rows = false;
+#pragma omp parallel for reduction(&& : ok_rows) num_threads(host_threads()) if (nrows > (1 << 20))
+    for (int64_t t = 0; t < nrows; ++t) ok_rows = ok_rows && S->sn_rows[(size_t)t] >= 0 && S->sn_rows[(size_t)t] < n;
+    const int64_t nasm = (int64_t)S->asm_dst.size();
+#pragma omp parallel for reduction(&& : ok_asm) num_threads(host_threads()) if (nasm > (1 << 20))
+    for (int64_t t = 0; t < nasm; ++t) ok_asm = ok_asm && S->asm_dst[(size_t)t] >= 0 && S->asm_dst[(size_t)t] < nst;
+    for (int64_t j = 0; j < n && ok_asm; ++j) ok_asm = S->diag_dst[(size_t)j] >= 0 && S->diag_dst[(size_t)j] < nst;
+    sane = ok_perm && ok_rows && ok_asm;
+  }
   if (!sane) { delete S; return nullptr; }
   S->combos_built = false;
   // (tile combo arrays of a fresh analysis are sized by build_tile_combos on demand)

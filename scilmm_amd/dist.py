@@ -91,7 +91,17 @@ class HipChainEngine(object):
         self._cb = _lib.COMM_FN(_comm)  # keep the callback object alive as long as the engine
         # (cache: a directory -- /dev/shm on one node -- where the first rank to analyse the pattern leaves the image of the
         #  analysis for the others: scilmm_symbolic_save / _load)
-        self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False, cache=cache)
+        if cache and dist is not None and world > 1:
+            # ONE writer per cache: rank 0 analyses the pattern and publishes the image, the others load it after the barrier
+            # (ranks missing the cache together would each analyse and each write the same image: correct -- the library
+            # writes under a private name and renames -- but world x the work and the memory)
+            if rank == 0:
+                self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False, cache=cache)
+            dist.barrier()
+            if rank != 0:
+                self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False, cache=cache)
+        else:
+            self.sym = Symbolic(mats, perm=perm, ordering=ordering, upload=False, cache=cache)
         L = _lib.lib()
         _lib.check(L.scilmm_dist_init(self.sym._h, rank, world, C.c_void_p(self._comm_stream.cuda_stream), self._cb, None), self.sym._h)
         self.sym.upload_values()
@@ -110,8 +120,7 @@ class HipChainEngine(object):
                                                    C.c_void_p(self._bufs[1].data_ptr()),
                                                    C.c_void_p(self._bufs[2].data_ptr()), C.byref(h)), self.sym._h)
         from .factor import Factor
-        self.fac = Factor.__new__(Factor)
-        self.fac.sym, self.fac.n, self.fac._h, self.fac._s2 = self.sym, self.sym.n, h, None
+        self.fac = Factor.from_handle(self.sym, h)
         self.n = self.sym.n
 
     def _guard(self, fn, *a):
@@ -159,6 +168,18 @@ class HipChainEngine(object):
         self._guard(self.sym.sync)
         return dZ
 
+    @property
+    def front_bits(self):
+        return getattr(self.sym, "front_bits", 64)
+
+    def spmm_t(self, k, dX):
+        """A_k X for a device block (n x r, any r): the residual of a refinement sweep (scilmm_spmm_dev)."""
+        dY = self.torch.empty_like(dX)
+        self.torch.cuda.synchronize(self.device)
+        self.sym.spmm_dev(k, C.c_void_p(dX.data_ptr()), dX.shape[1], C.c_void_p(dY.data_ptr()))
+        self.sym.sync()
+        return dY
+
     def quadforms_t(self, k, dQ):
         dq = self.torch.empty(dQ.shape[1], dtype=self.torch.float64, device=self.device)
         self.torch.cuda.synchronize(self.device)
@@ -175,9 +196,64 @@ class DistributedEvaluator(object):
     a streaming pass over the replicated A_k values -- are split by COLUMNS over the ranks and all-gathered.
     Every rank returns the same (nll, grad)."""
 
-    def __init__(self, engine, mats, C_cov, y, rank, world, dist=None, device=None):
+    REFINE_STEPS = 2  # (as scilmm_amd.factor.Factor.REFINE_STEPS: each sweep gains ~7 digits on a factor with fp32-product fronts)
+
+    def __init__(self, engine, mats, C_cov, y, rank, world, dist=None, device=None, refine_steps=None):
+        """``refine_steps``: iterative-refinement sweeps of the fused solve against the exact V = sum_k sigma2_k A_k.  None =
+        what the factor needs: ``REFINE_STEPS`` when the engine runs fp32-product fronts (``front_bits == 32``, BASELINE
+        configs[4]), none on an fp64 factor."""
         self.engine, self.mats, self.C, self.y = engine, mats, np.asarray(C_cov, float), np.asarray(y, float)
         self.rank, self.world, self.dist, self.device = rank, world, dist, device
+        self.refine_steps = refine_steps
+        self.last_refinement = []   # max |correction| / max |x| of every sweep of the last evaluation (diagnostics, tests)
+
+    def _apply_V(self, s2, X, on_dev):
+        """V X = sum_k sigma2_k A_k X for an n x r block that every rank holds, with the COLUMNS split over the ranks (a
+        streaming pass over the replicated A_k values per column, as for the quadratic forms) and the column blocks put
+        together again by one all-reduce of the zero-padded block -- the residual of a refinement sweep, the counterpart
+        of ``_finish_on_device``'s K x ``spmm_dev`` (SparseCholesky.py) on the multi-rank path."""
+        eng = self.engine
+        r = X.shape[1]
+        q0, q1 = column_chunks(r, self.world)[self.rank]
+        if on_dev:
+            torch = eng.torch
+            out = torch.zeros_like(X)
+            if q1 > q0:
+                mine = X[:, q0:q1].contiguous()
+                acc = None
+                for k in range(len(self.mats)):
+                    t = eng.spmm_t(k, mine)
+                    acc = t.mul_(float(s2[k])) if acc is None else acc.add_(t, alpha=float(s2[k]))
+                out[:, q0:q1] = acc
+            if self.world > 1 and self.dist is not None:
+                torch.cuda.synchronize(eng.device)
+                self.dist.all_reduce(out)
+                torch.cuda.synchronize(eng.device)
+            return out
+        out = np.zeros_like(X)
+        if q1 > q0:
+            mine = np.ascontiguousarray(X[:, q0:q1])
+            for k in range(len(self.mats)):
+                out[:, q0:q1] += float(s2[k]) * np.asarray(eng.spmm(k, mine))
+        if self.world > 1 and self.dist is not None:
+            import torch
+            self.dist.all_reduce(torch.from_numpy(out))
+        return out
+
+    def _refined_solve(self, s2, B, on_dev):
+        """X = V^-1 B through the collective sweeps, followed by ``refine_steps`` sweeps x += V^-1 (B - V x)."""
+        eng = self.engine
+        X = eng.solve_t(B) if on_dev else eng.solve(B)
+        steps = self.refine_steps
+        if steps is None:
+            steps = self.REFINE_STEPS if getattr(eng, "front_bits", 64) == 32 else 0
+        self.last_refinement = []
+        for _ in range(steps):
+            res = B - self._apply_V(s2, X, on_dev)
+            dx = eng.solve_t(res) if on_dev else eng.solve(res)
+            self.last_refinement.append(float(abs(dx).max() / abs(X).max()))
+            X = X + dx
+        return X
 
     def _gather_vec(self, local, chunks):
         """local: this rank's slice of a length-r vector (host array) -> the full vector on every rank."""
@@ -204,13 +280,13 @@ class DistributedEvaluator(object):
             torch = eng.torch
             dZ = eng.lmul_t(torch.from_numpy(R).to(eng.device))
             head = torch.from_numpy(np.ascontiguousarray(np.hstack([self.C, self.y[:, None]]))).to(eng.device)
-            dX = eng.solve_t(torch.cat([head, dZ], dim=1).contiguous())
+            dX = self._refined_solve(s2, torch.cat([head, dZ], dim=1).contiguous(), True)
             del dZ
             Xh = dX[:, :c + 1].cpu().numpy()
             ViC, Viy0 = Xh[:, :c], Xh[:, c]
         else:
             Z = eng.lmul(R)
-            X = eng.solve(np.hstack([self.C, self.y[:, None], Z]))
+            X = self._refined_solve(s2, np.hstack([self.C, self.y[:, None], Z]), False)
             ViC, Viy0, U = X[:, :c], X[:, c], X[:, c + 1:]
         G = la.cho_factor(self.C.T @ ViC)
         beta = la.cho_solve(G, self.C.T @ Viy0)

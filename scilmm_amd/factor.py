@@ -18,7 +18,26 @@ from ._lib import check, lib, ptr
 _ORDERINGS = {"amd": 0, "natural": 1, "given": 2, "nesdis": 3, "best": 4}
 
 
+class PatternCSR(object):
+    """A CSR sparsity pattern WITHOUT values (canonical: rows ascending, both halves stored): what ``Symbolic`` needs of a
+    matrix whose values are then computed on the device (``ibd_values_from_pedigree``, ``dominance_values_from``) -- at
+    BASELINE configs[4]'s 3M pedigree that is 21.6 GB of values per matrix that never exist on the host."""
+
+    has_sorted_indices = True
+    data = None
+
+    def __init__(self, indptr, indices, n):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.shape = (int(n), int(n))
+        if self.indptr.shape != (n + 1,) or int(self.indptr[-1]) != self.indices.size:
+            raise ValueError("indptr / indices do not describe an n x n CSR pattern")
+        self.nnz = int(self.indices.size)
+
+
 def _as_csr(m):
+    if isinstance(m, PatternCSR):
+        return m
     m = sp.csr_matrix(m)
     if not m.has_sorted_indices:
         m = m.sorted_indices()
@@ -37,7 +56,7 @@ class Symbolic(object):
         self.K = K = len(mats)
         self._indptr = [np.ascontiguousarray(m.indptr, dtype=np.int64) for m in mats]
         self._indices = [np.ascontiguousarray(m.indices, dtype=np.int32) for m in mats]
-        self._data = [np.ascontiguousarray(m.data, dtype=np.float64) for m in mats]
+        self._data = [None if m.data is None else np.ascontiguousarray(m.data, dtype=np.float64) for m in mats]
         self._values_epoch = 0  # bumped whenever the resident values of a matrix change (Factor.holds)
         if perm is not None:
             ordering = "given"
@@ -71,23 +90,39 @@ class Symbolic(object):
         if upload:
             self.upload_values()
 
+    # every environment variable the host analysis reads (csrc/symbolic.cpp, csrc/capi_symbolic.cpp): part of the cache key
+    _ANALYSIS_ENV = ("SCILMM_TUNING", "SCILMM_TAIL_WIDE", "SCILMM_TAIL_ELIG", "SCILMM_TAIL_DELAY")
+    # bumped whenever the analysis changes what it produces for the same input (the library's magic number guards the FORMAT of
+    # the image, this constant and scilmm_version() its CONTENT)
+    _ANALYSIS_REVISION = 4
+
     def _analysis_key(self, n, perm, ordering, opts):
-        import xxhash
-        hx = xxhash.xxh64()
-        hx.update(np.array([n, self.K, _ORDERINGS[ordering]], dtype=np.int64).tobytes())
+        """64-bit key of everything the analysis depends on: patterns, permutation, ordering, options, the environment
+        variables it reads, the library version and the analysis revision.  xxhash when it is installed (0.5 s per 4 GB of
+        pattern), hashlib.blake2b otherwise (standard library: no dependency is needed for the cache to work)."""
+        try:
+            import xxhash
+            hx = xxhash.xxh64()
+            digest = hx.intdigest
+        except ImportError:
+            import hashlib
+            hx = hashlib.blake2b(digest_size=8)
+            digest = lambda: int.from_bytes(hx.digest(), "little")
+        hx.update(np.array([n, self.K, _ORDERINGS[ordering], self._ANALYSIS_REVISION], dtype=np.int64).tobytes())
+        hx.update(lib().scilmm_version())
         hx.update(repr(sorted(opts.items())).encode())
-        hx.update(repr(sorted((k, v) for k, v in os.environ.items() if k in ("SCILMM_TUNING", "SCILMM_TAIL_WIDE"))).encode())
+        hx.update(repr(sorted((k, v) for k, v in os.environ.items() if k in self._ANALYSIS_ENV)).encode())
         if perm is not None:
             hx.update(perm.tobytes())
         for ip, ix in zip(self._indptr, self._indices):
-            hx.update(ip.tobytes())
-            hx.update(ix.tobytes())
-        return hx.intdigest()
+            hx.update(memoryview(ip).cast("B"))
+            hx.update(memoryview(ix).cast("B"))
+        return digest()
 
     def upload_values(self, skip=()):
         self._values_epoch += 1
         for k in range(self.K):
-            if k not in skip:
+            if k not in skip and self._data[k] is not None:  # (None: a PatternCSR -- its values are built on the device)
                 check(lib().scilmm_values_upload(self._h, k, ptr(self._data[k])), self._h)
         self._uploaded = True
 
@@ -101,6 +136,16 @@ class Symbolic(object):
             raise ValueError("parents must be an (n, 2) table")
         self._values_epoch += 1
         check(lib().scilmm_ibd_values_device(self._h, k, self.n, ptr(par)), self._h)
+
+    def dominance_values_from(self, k_dst, k_src, parents):
+        """Compute matrix ``k_dst``'s values -- the dominance relationship matrix of the pedigree ``parents`` on the analysed
+        pattern (reference scilmm/Matrices/Dominance.py:12-43) -- ON THE DEVICE from matrix ``k_src``'s resident IBD values,
+        straight into its value slots (``scilmm_dominance_values_device``)."""
+        par = np.ascontiguousarray(parents, dtype=np.int32)
+        if par.shape != (self.n, 2):
+            raise ValueError("parents must be an (n, 2) table")
+        self._values_epoch += 1
+        check(lib().scilmm_dominance_values_device(self._h, k_dst, k_src, self.n, ptr(par)), self._h)
 
     def values_slots(self, k):
         """Matrix k's device-resident values in pattern-slot order (tests, diagnostics)."""
@@ -213,9 +258,18 @@ class Factor(object):
         bad = C.c_int32(-1)
         st = lib().scilmm_factorize(symbolic._h, ptr(s2), C.byref(h), C.byref(bad))
         self._h = h
-        self._s2 = None
+        self._s2, self._epoch, self._pending = None, -1, None
         check(st, symbolic._h, bad.value)
         self._s2, self._epoch = s2.copy(), symbolic._values_epoch
+
+    @classmethod
+    def from_handle(cls, symbolic, handle):
+        """A Factor object around an existing ``scilmm_factor*`` (caller-owned storage: ``scilmm_factor_create_external``,
+        the multi-GPU engine); nothing is factorized yet."""
+        f = cls.__new__(cls)
+        f.sym, f.n, f._h = symbolic, symbolic.n, handle
+        f._s2, f._epoch, f._pending = None, -1, None
+        return f
 
     def holds(self, sigma2):
         """True when this object IS the factor of sum_k sigma2[k] A_k for the values now resident (so that a caller -- the
@@ -226,7 +280,7 @@ class Factor(object):
     def refactorize(self, sigma2):
         s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
         bad = C.c_int32(-1)
-        self._s2 = None
+        self._s2, self._pending = None, None  # (a recorded async request is superseded: its sigma2 must never be adopted later)
         check(lib().scilmm_refactorize(self._h, ptr(s2), C.byref(bad)), self.sym._h, bad.value)
         self._s2, self._epoch = s2.copy(), self.sym._values_epoch
         return self
@@ -234,16 +288,17 @@ class Factor(object):
     def refactorize_async(self, sigma2):
         """Queue the refactorization and return; ``wait()`` (or any use of the factor) completes it."""
         s2 = np.ascontiguousarray(sigma2, dtype=np.float64)
-        self._s2 = None
+        self._s2, self._pending = None, None
         check(lib().scilmm_refactorize_async(self._h, ptr(s2)), self.sym._h)
         self._pending = (s2.copy(), self.sym._values_epoch)
         return self
 
     def wait(self):
         bad = C.c_int32(-1)
-        check(lib().scilmm_factor_wait(self._h, C.byref(bad)), self.sym._h, bad.value)
-        if getattr(self, "_pending", None) is not None:
-            (self._s2, self._epoch), self._pending = self._pending, None
+        pending, self._pending = getattr(self, "_pending", None), None  # cleared whatever happens: a failed factorization
+        check(lib().scilmm_factor_wait(self._h, C.byref(bad)), self.sym._h, bad.value)  # (raises) leaves no sigma2 behind
+        if pending is not None:
+            self._s2, self._epoch = pending
         return self
 
     def __del__(self):
@@ -296,7 +351,9 @@ class Factor(object):
         """tr(V^-1 A_k) for every matrix of the analysis, exactly: the selected inverse on the supernodal factor (Takahashi
         recursion on the device, in place) followed by one pass over each A_k's pattern.  CONSUMES the factor: it must be
         refactorized before the next solve."""
-        self._s2 = None  # (the panels hold entries of the inverse from here on)
+        if getattr(self, "_pending", None) is not None:
+            self.wait()
+        self._s2, self._pending = None, None  # (the panels hold entries of the inverse from here on)
         check(lib().scilmm_selected_inverse(self._h), self.sym._h)
         out = np.empty(self.sym.K)
         check(lib().scilmm_inverse_traces(self._h, ptr(out)), self.sym._h)

@@ -28,9 +28,10 @@ def count_ibd_nonzero(par):
     return nnz.value
 
 
-def ibd_pattern_from_parents(par):
+def ibd_pattern_from_parents(par, values=True):
     """The PATTERN of A (pairs with a common ancestor; both triangles, sorted) as a CSR matrix of ones -- no values are
-    computed: they can be produced on the device (``Symbolic.ibd_values_from_pedigree``)."""
+    computed: they can be produced on the device (``Symbolic.ibd_values_from_pedigree``).  ``values=False``: a
+    ``scilmm_amd.factor.PatternCSR`` (no value array at all: 8 bytes per entry less on the host)."""
     par = _parents32(par)
     n = par.shape[0]
     h, nnz = C.c_void_p(), C.c_int64(0)
@@ -40,6 +41,9 @@ def ibd_pattern_from_parents(par):
         check(lib().scilmm_ibd_export(h, ptr(ap), ptr(ai), None, None, None, None, None, None))
     finally:
         lib().scilmm_ibd_free(h)
+    if not values:
+        from .factor import PatternCSR
+        return PatternCSR(ap, ai, n)
     return sp.csr_matrix((np.ones(nnz.value), ai, ap), shape=(n, n))
 
 

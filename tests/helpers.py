@@ -21,6 +21,19 @@ def small_pedigree(n, sf, seed=0):
     return A2, sex2
 
 
+def small_pedigree_k3(n, sf, seed=0):
+    """(A, D, sex) after the unrelated-drop: additive + dominance matrix of one simulated pedigree (BASELINE configs[4]'s
+    model); D from the NumPy restatement of reference scilmm/Matrices/Dominance.py:12-43 (host only: usable without a GPU)."""
+    from scilmm_amd.harness.pedigree import simulate_pedigree, ibd_from_parents, drop_unrelated, dominance_from_parents
+    par, sex, _ = simulate_pedigree(n, sf, seed)
+    A = ibd_from_parents(par)
+    D = dominance_from_parents(par, A)
+    A2, has, sex2 = drop_unrelated(A, sex)
+    D2 = D[has][:, has].tocsr()
+    D2.sort_indices()
+    return A2, D2, sex2
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

@@ -7,7 +7,7 @@ import socket
 import numpy as np
 import scipy.sparse as sp
 
-from tests.helpers import small_pedigree
+from tests.helpers import small_pedigree, small_pedigree_k3
 
 
 def _free_port():
@@ -95,16 +95,25 @@ def test_partition_keeps_components_whole():
 #      (scilmm_amd/dist.py; the CPU stand-in oracle/dist_cpu.py reads the distribution rule from the library)
 
 def _tail_problem(which):
-    n0, sf, seed = {"24panels": (20000, 0.01, 1), "39panels": (30000, 0.01, 2)}[which]
-    A, sex = small_pedigree(n0, sf, seed)
+    n0, sf, seed = {"24panels": (20000, 0.01, 1), "39panels": (30000, 0.01, 2), "24panels_k3": (20000, 0.01, 1)}[which]
+    if which.endswith("_k3"):
+        A, D, sex = small_pedigree_k3(n0, sf, seed)   # K = 3: additive + dominance + identity (BASELINE configs[4]'s model)
+        mats = [A, D]
+    else:
+        A, sex = small_pedigree(n0, sf, seed)
+        mats = [A]
     n = A.shape[0]
     rng = np.random.default_rng(2)
     y = rng.standard_normal(n)
     C = np.stack([(sex - sex.mean()) / sex.std(), np.ones(n)], axis=1)
-    return [A, sp.eye(n).tocsr()], C, y
+    return mats + [sp.eye(n).tocsr()], C, y
 
 
-def _tail_worker(rank, world, port, out, which, group):
+def _sigma2_of(which):
+    return [0.3, 0.15, 0.5] if which.endswith("_k3") else [0.45, 0.5]
+
+
+def _tail_worker(rank, world, port, out, which, group, refine=None):
     import torch
     import torch.distributed as dist
     torch.set_num_threads(1)
@@ -121,25 +130,26 @@ def _tail_worker(rank, world, port, out, which, group):
     from scilmm_amd.dist import DistributedEvaluator
     mats, C, y = _tail_problem(which)
     eng = CpuChainEngine(mats, rank, world, dist)
-    ev = DistributedEvaluator(eng, mats, C, y, rank, world, dist)
+    ev = DistributedEvaluator(eng, mats, C, y, rank, world, dist, refine_steps=refine)
     res = []
     for reml in (True, False):
         np.random.seed(4)
-        res.append(ev.evaluate(np.log([0.45, 0.5]), reml=reml, sim_num=20))
+        res.append(ev.evaluate(np.log(_sigma2_of(which)), reml=reml, sim_num=20))
     np.savez(out % rank, nll=np.array([r[0] for r in res]), grad=np.array([r[1] for r in res]), first=eng.first, Wg=eng.Wg,
+             refinement=np.array(ev.last_refinement),
              G=eng.G, nT=eng.nT, computed=eng.panels_computed, received=eng.panels_received, batches=eng.batches,
              local=eng.local_doubles, total=eng.global_doubles, ns=eng.ns, perm=eng.perm, owner=eng.owner,
              collectives=eng.collectives)
     dist.destroy_process_group()
 
 
-def _check_tail_run(tmp_path, world, which, group, reference):
+def _check_tail_run(tmp_path, world, which, group, reference, refine=None):
     import torch.multiprocessing as mp
     from oracle import oracle as O
     from oracle import reml_oracle as RO
     from scilmm_amd.factor import Symbolic
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_tail_worker, args=(world, _free_port(), out, which, group), nprocs=world, join=True)
+    mp.spawn(_tail_worker, args=(world, _free_port(), out, which, group, refine), nprocs=world, join=True)
     got = [np.load(out % r) for r in range(world)]
     mats, C, y = _tail_problem(which)
     perm = got[0]["perm"]
@@ -152,7 +162,7 @@ def _check_tail_run(tmp_path, world, which, group, reference):
         factor_of = None  # the simplicial C oracle
     for i, reml in enumerate((True, False)):
         np.random.seed(4)
-        nll, grad = RO.evaluate(np.log([0.45, 0.5]), mats, C, y, reml, 20, perm=perm, factor_of=factor_of)
+        nll, grad = RO.evaluate(np.log(_sigma2_of(which)), mats, C, y, reml, 20, perm=perm, factor_of=factor_of)
         for g in got:  # every rank ends with the same numbers
             assert abs(g["nll"][i] - nll) < 1e-10 * abs(nll)
             assert np.abs(g["grad"][i] - grad).max() < 1e-8 * np.abs(grad).max()
@@ -192,6 +202,17 @@ def test_eight_rank_distributed_tail(tmp_path):
     got = _check_tail_run(tmp_path, 8, "39panels", 0, "port")
     # every rank issued the same sequence of collectives
     assert len({int(g["collectives"]) for g in got}) == 1
+
+
+def test_eight_rank_k3_with_refinement_sweeps(tmp_path):
+    """BASELINE configs[4]'s model and control flow at its rank count: K = 3 (A + D + I), 24 tail panels over 8 ranks, and
+    the refinement sweeps a factor with fp32-product fronts needs (residual V x by K column-split SpMMs + one all-reduce,
+    one more collective solve per sweep) -- forced here on the fp64 CPU factor, where a sweep must change nothing: the
+    evaluation still matches the single-process oracle, and the corrections are at rounding level."""
+    got = _check_tail_run(tmp_path, 8, "24panels_k3", 0, "port", refine=2)
+    assert len({int(g["collectives"]) for g in got}) == 1
+    for g in got:
+        assert g["refinement"].shape == (2,) and g["refinement"].max() < 1e-12
 
 
 def _npd_worker(rank, world, port, out):

@@ -522,7 +522,7 @@ def test_k3_additive_dominance_fp32_fronts_100k(monkeypatch):
     from oracle import oracle as O
     from scilmm_amd.harness.pedigree import make_problem
     monkeypatch.setenv("SCILMM_TUNING", "1")
-    monkeypatch.setenv("SCILMM_DENSE", "1")  # the 100k tail (16k columns) is narrower than the automatic threshold
+    monkeypatch.setenv("SCILMM_DENSE", "1")  # (pins the dense-tail path; it is also the default at this width: threshold 8192 columns)
     mats, C, y = make_problem(100000, 0.005, seed=0, with_dominance="device")
     A, D = mats
     n = A.shape[0]
@@ -619,6 +619,53 @@ def test_ibd_values_built_on_the_device_match_reference_goldens_bit_for_bit():
             assert f.logdet() == ref.logdet()
     with pytest.raises(Exception):
         sym.ibd_values_from_pedigree(0, par[::-1].copy())   # not in pedigree order
+
+
+def test_dominance_values_built_on_the_device_in_slot_order_bit_for_bit():
+    """BASELINE configs[4]'s second variance component built where it is used (`scilmm_dominance_values_device`): from a
+    value-less pattern (PatternCSR) and the parent table, A by the tabular recursion and D from A's resident slots.
+    Bit-exact against the matrix the REFERENCE's own `dominance(rel, ibd)` produced (golden G2, on G1's pedigree) and
+    against the CSR-layout kernel on a 100k pedigree; the factor of A + D + I built this way equals the uploaded one."""
+    import os
+    from scilmm_amd import _lib, ibd
+    from scilmm_amd.factor import PatternCSR
+    from scilmm_amd.Matrices.Dominance import parents_of
+    from scilmm_amd.harness import pedigree as H
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g1 = np.load(os.path.join(gold, "G1_reml_2000.npz"))
+    g2 = np.load(os.path.join(gold, "G2_lmm_dominance.npz"))
+    shape = tuple(g1["A_shape"])
+    A1 = sp.csr_matrix((g1["A_data"], g1["A_indices"], g1["A_indptr"]), shape=shape)
+    D1 = sp.csr_matrix((g2["D_data"], g2["D_indices"], g2["D_indptr"]), shape=shape)   # (zero coefficients dropped, as the reference does)
+    par1 = parents_of(sp.csr_matrix((g2["rel_data"], g2["rel_indices"], g2["rel_indptr"]), shape=shape))
+    parL, _, _ = H.simulate_pedigree(100000, 0.005, seed=0)
+    AL = ibd.ibd_from_parents(parL)
+    for Aref, Dref, par in [(A1, D1, par1), (AL, _lib.dominance(AL, parL), parL)]:
+        n = Aref.shape[0]
+        P = ibd.ibd_pattern_from_parents(par, values=False)
+        assert isinstance(P, PatternCSR) and P.data is None and P.nnz == Aref.nnz
+        I = sp.identity(n, format="csr")
+        sym = _engine([P, P, I], upload=False)
+        sym.upload_values()                       # (only the identity has host values)
+        with pytest.raises(_lib.ScilmmError):
+            sym.dominance_values_from(1, 0, par)  # A's values are not resident yet
+        sym.ibd_values_from_pedigree(0, par)
+        sym.dominance_values_from(1, 0, par)
+        perm, colptr, prow = sym.get("perm"), sym.get("pat_colptr"), sym.get("pat_row")
+        for k, M in ((0, Aref), (1, Dref)):
+            got = sp.csc_matrix((sym.values_slots(k), prow, colptr), shape=(n, n))
+            got.eliminate_zeros()
+            want = sp.tril(M.tocsr()[perm][:, perm]).tocsc()
+            want.eliminate_zeros()
+            want.sort_indices()
+            got.sort_indices()
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices), k
+            assert np.array_equal(got.data, want.data), (k, np.abs(got.data - want.data).max())
+        f = sym.factorize([0.3, 0.1, 0.6])
+        Dfull = Dref if Dref.nnz == Aref.nnz else sp.csr_matrix(Dref + 0 * Aref)   # (same pattern => same analysis)
+        ref = _engine([Aref, Dfull, I]).factorize([0.3, 0.1, 0.6])
+        # (same assembled values; the 100k schedule sums its prelude -> tail contributions with atomics: rounding-level only)
+        assert np.array_equal(f.P(), ref.P()) and abs(f.logdet() - ref.logdet()) <= (0.0 if n <= 2000 else 1e-12) * abs(ref.logdet())
 
 
 def test_integration_stub_from_the_document_runs():

@@ -279,6 +279,35 @@ def test_front_bits_option_of_the_drop_in_class(monkeypatch):
         M.SparseCholesky(front_bits=16)
 
 
+@pytest.mark.parametrize("bits", [64, 32])
+def test_device_resident_evaluation_equals_host_buffer_path(monkeypatch, bits):
+    """one evaluation with the n x 100 blocks kept in HBM (`_finish_on_device`: torch buffers + the `_dev` entry
+    points, refinement on the device when the fronts are fp32 products) against the SAME evaluation through host buffers
+    (SCILMM_HOST_BUFFERS=1: `Factor.__call__` / `lmul` / `quadforms`, refinement through the host).  fp64: the two run the same
+    kernels on the same numbers -- nll 1e-12, gradient 1e-10; fp32-product fronts: both refine twice against the exact V and
+    land on the same solution to the conditioning of V (nll 1e-10, gradient 1e-8; the unrefinable log-det is the same number)."""
+    from scilmm_amd.harness import pedigree as H
+    monkeypatch.setenv("SCILMM_TUNING", "1")
+    monkeypatch.setenv("SCILMM_DENSE", "1")   # (fp32 fronts need the dense-tail path; a 10k pedigree's tail is below the automatic threshold)
+    mats, C, y = H.make_problem(10000, 0.01, seed=2)
+    mats = mats + [sp.identity(y.size, format="csr")]
+    x0 = np.log(np.array([0.45, 0.5]))
+    out = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("SCILMM_HOST_BUFFERS", "1")
+        else:
+            monkeypatch.delenv("SCILMM_HOST_BUFFERS", raising=False)
+        assert (P._device_buffers() is None) == host
+        chol = P.SparseCholesky(front_bits=bits)
+        np.random.seed(3)
+        out[host] = P.bolt_gradient_estimation(x0, chol, mats, C, y, True, 50, False)
+        assert getattr(chol.engine_for(mats), "front_bits", 64) == bits
+        chol.release_factors()
+    assert abs(out[True][0] - out[False][0]) < (1e-12 if bits == 64 else 1e-10) * abs(out[False][0])
+    assert rel_err(out[True][1], out[False][1]) < (1e-10 if bits == 64 else 1e-8)
+
+
 def test_selected_inverse_traces_at_100k_against_identity_solves():
     """The selected inverse at BASELINE configs[1]'s size (100k individuals, K = 2; 1.7 TFLOP factor, 3.4 TFLOP inversion):
     tr(V^-1 A) and tr(V^-1) against the brute-force form (163 multi-column sweeps of the factor, 55 GB over PCIe) to 1e-8,

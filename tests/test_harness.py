@@ -117,6 +117,66 @@ def test_native_matrix_market_reader_matches_scipy(tmp_path):
             _lib.read_matrix_market(str(bad))
 
 
+def test_relationship_matrix_reader_never_hides_a_parse_error(tmp_path):
+    """`read_relationship_matrix` (reference SparseCholesky.py:399): array-format files go to SciPy's reader BY THEIR BANNER;
+    a malformed coordinate file raises instead of being retried through scipy.io.mmread (VERDICT r3 weak #15)."""
+    import importlib
+    import scipy.io as sio
+    from scilmm_amd import _lib
+    P = importlib.import_module("scilmm_amd.SparseCholesky")
+    dense = tmp_path / "dense.mtx"
+    sio.mmwrite(str(dense), np.array([[2.0, 1.0], [1.0, 3.0]]))          # array format
+    got = P.read_relationship_matrix(str(dense))
+    assert np.array_equal(got.toarray(), [[2.0, 1.0], [1.0, 3.0]])
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")   # one entry short
+    with pytest.raises(_lib.ScilmmError):
+        P.read_relationship_matrix(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n1 x 1.0\n")
+    with pytest.raises(_lib.ScilmmError):
+        P.read_relationship_matrix(str(bad))
+
+
+def test_symbolic_image_survives_concurrent_writers_and_rejects_damage(tmp_path):
+    """ADVICE r3: the image of an analysis is written under a private temporary name (several processes saving the same key
+    cannot tear each other's file), carries a length + checksum trailer, and a truncated / altered / padded file is a cache
+    miss (fresh analysis), never a wrong analysis."""
+    import multiprocessing as mp
+    from scilmm_amd.factor import Symbolic
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(3000, 0.003, 5)
+    mats = [A, sp.identity(A.shape[0], format="csr")]
+    cache = str(tmp_path / "cache")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_save_image_worker, args=(cache,)) for _ in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    files = os.listdir(cache)
+    assert len(files) == 1 and files[0].endswith(".bin")       # no temporary left behind
+    ref = Symbolic(mats, upload=False)
+    hit = Symbolic(mats, upload=False, cache=cache)
+    assert hit.from_cache and np.array_equal(hit.P(), ref.P()) and np.array_equal(hit.get("asm_dst"), ref.get("asm_dst"))
+    path = os.path.join(cache, files[0])
+    blob = open(path, "rb").read()
+    for damaged in (blob[:len(blob) // 2], blob[:-8], blob + b"\0" * 8,
+                    blob[:len(blob) // 2] + bytes([blob[len(blob) // 2] ^ 1]) + blob[len(blob) // 2 + 1:]):
+        open(path, "wb").write(damaged)
+        miss = Symbolic(mats, upload=False, cache=cache)
+        assert not miss.from_cache and np.array_equal(miss.P(), ref.P())
+        assert open(path, "rb").read() == blob                   # ... and the fresh analysis republished a good image
+
+
+def _save_image_worker(cache):
+    import scipy.sparse as sp_
+    from scilmm_amd.factor import Symbolic
+    from tests.helpers import small_pedigree
+    A, _ = small_pedigree(3000, 0.003, 5)
+    Symbolic([A, sp_.identity(A.shape[0], format="csr")], upload=False, cache=cache)
+
+
 def test_quick_id_sees_in_place_edits():
     """The engine cache of the drop-in `SparseCholesky` keys on a full-pass checksum of the value arrays: an in-place
     edit of one entry, a sign flip and a swap of two entries must all change it (ADVICE r1), identical content must not."""

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from tests.helpers import rel_err, small_pedigree
+from tests.helpers import rel_err, small_pedigree, small_pedigree_k3
 
 pytestmark = pytest.mark.gpu
 
@@ -121,6 +121,78 @@ def test_distributed_tail_with_fp32_product_fronts(tmp_path):
         assert rel_err(g["X2"], f2(B)) < 1e-5 and rel_err(g["Z2"], f2.lmul(B)) < 1e-5
     # every rank ends with the same result (to rounding: the replicated prelude sums its tail contributions with atomics)
     assert rel_err(got[0]["X"], got[1]["X"]) < 1e-12 and abs(got[0]["logdet"] - got[1]["logdet"]) < 1e-10 * abs(got[0]["logdet"])
+
+
+def _problem_k3():
+    A, D, sex = small_pedigree_k3(20000, 0.01, 1)   # 24 tail panels; K = 3: additive + dominance + identity
+    n = A.shape[0]
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal(n)
+    C = np.stack([(sex - sex.mean()) / sex.std(), np.ones(n)], axis=1)
+    return [A, D, sp.eye(n).tocsr()], C, y
+
+
+K3_SIGMA2 = [0.3, 0.15, 0.5]
+
+
+def _k3_worker(rank, world, port, out, env):
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)
+    os.environ.update(env)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scilmm_amd.dist import DistributedEvaluator, HipChainEngine
+    mats, C, y = _problem_k3()
+    eng = HipChainEngine(mats, rank, world, dist, "cuda:0")
+    eng.sym.set_front_precision(32)
+    ev = DistributedEvaluator(eng, mats, C, y, rank, world, dist, device="cpu")
+    np.random.seed(4)
+    nll, grad = ev.evaluate(np.log(K3_SIGMA2), reml=True, sim_num=50)
+    steps = np.array(ev.last_refinement)
+    B = np.random.default_rng(0).standard_normal((y.size, 7))
+    dB = torch.from_numpy(B).to("cuda:0")
+    X_raw = eng.solve_t(dB).cpu().numpy()                           # the fp32-product factor's own solve
+    X_ref = ev._refined_solve(np.array(K3_SIGMA2), dB, True).cpu().numpy()
+    np.savez(out % rank, nll=nll, grad=grad, logdet=eng.logdet(), X_raw=X_raw, X_ref=X_ref, steps=steps, perm=eng.P())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs4_model_on_two_ranks_k3_fp32_fronts_refined(tmp_path):
+    """BASELINE configs[4]'s model AND arithmetic on the multi-rank path: K = 3 (A + D + I), fp32-product
+    fronts on the distributed tail, the fused solve REFINED on the device against the exact V (column-split SpMMs + one
+    all-reduce, one more collective sweep per step) -- against the fp64 simplicial oracle with the same P and np.random stream.
+    Tolerances: refined solves 1e-10, gradient 1e-7 (it is made of refined solves only).  The log-det of a factor with fp32
+    products is NOT refinable (it is the log-det of V + E, |E| ~ 1e-7 |V| entrywise in the tail): nll is held to 1e-8 --
+    measured 1e-9 at 1M -- and the raw solve's error (> 1e-9) shows that the fp32 products did run."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from oracle import reml_oracle as RO
+    from scilmm_amd.factor import Symbolic
+    world = 2
+    out = str(tmp_path / "k3rank%d.npz")
+    mp.spawn(_k3_worker, args=(world, _free_port(), out, {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "2"}), nprocs=world, join=True)
+    got = [np.load(out % r) for r in range(world)]
+    mats, C, y = _problem_k3()
+    perm = Symbolic(mats, upload=False).P()
+    V = sum(a * m for a, m in zip(K3_SIGMA2, mats)).tocsr()
+    o = O.OracleFactor(V, perm)
+    B = np.random.default_rng(0).standard_normal((y.size, 7))
+    X = o(B)
+    np.random.seed(4)
+    nll, grad = RO.evaluate(np.log(K3_SIGMA2), mats, C, y, True, 50, perm=perm)
+    for g in got:
+        assert np.array_equal(g["perm"], perm)
+        assert rel_err(g["X_ref"], X) < 1e-10
+        assert 1e-9 < rel_err(g["X_raw"], X) < 1e-4          # fp32 products ran; each refinement sweep gains ~7 digits
+        assert g["steps"].shape == (2,) and g["steps"][0] < 1e-4 and g["steps"][1] < 1e-9
+        assert abs(g["nll"] - nll) < 1e-8 * abs(nll)
+        assert rel_err(g["grad"], grad) < 1e-7
+        assert abs(g["logdet"] - o.logdet()) < 1e-6 * abs(o.logdet())
+    assert rel_err(got[0]["X_ref"], got[1]["X_ref"]) < 1e-12 and abs(got[0]["nll"] - got[1]["nll"]) < 1e-12 * abs(nll)
 
 
 def _npd_worker(rank, world, port, out):
