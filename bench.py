@@ -638,7 +638,7 @@ def main():
                            "of this workload aborts inside the profiler" % os.path.relpath(iso, ROOT))
         upd_s = prof["update_ms"] / 1e3
         n_upd = max(prof["n_update_launches"], 1)
-        ach_all = info.update_flops * K / max(upd_s, 1e-12) / 1e12
+        ach_all = info.update_flops * K / world / max(upd_s, 1e-12) / 1e12
         dense_on = prof["n_dense_launches"] > 0
         if dense_on:
             # dominant kernel = k_dense: ITS algorithmic flops (tail x tail updates, true structure) over ITS launches
@@ -648,7 +648,9 @@ def main():
                      "tail by the dense tail)") if args.front_bits == 32 else
                     "k_dense_b (fp64 MFMA update of the dense tail by the dense tail: A fragments from registers, B by LDS-DMA, "
                     "both streams software-pipelined in the wave)")
-            flops_k, n_k, ms_k = info.dense_flops * K, prof["n_dense_launches"], prof["dense_ms"]
+            # (N > 1: THIS rank's launches -- batches + late items -- against its 1 / N share of the tail's flops: the panels
+            #  are owned block-cyclically, so the shares are equal to a fraction of a percent)
+            flops_k, n_k, ms_k = info.dense_flops * K / world, prof["n_dense_launches"], prof["dense_ms"]
         else:
             kern = "k_update2<true> (fp64 MFMA supernodal update)"
             flops_k, n_k, ms_k = info.update_flops * K, n_upd, prof["update_ms"]
@@ -731,7 +733,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          # launches of consecutive levels overlap on two streams: the same flops over the time during
                          # which at least one update launch was running (not the figure the contract asks for)
-                         "achieved_over_busy_time": info.update_flops * K / max(prof["update_union_ms"] / 1e3, 1e-12) / 1e12,
+                         "achieved_over_busy_time": (info.update_flops * K / max(prof["update_union_ms"] / 1e3, 1e-12) / 1e12) if world == 1 else None,
+                         "rank": "rank 0 of %d: its own launches against 1/%d of the flops" % (world, world) if world > 1 else "the one GPU",
                          "flops_per_launch": flops_k / max(n_k, 1),
                          "avg_launch_ms": ms_k / max(n_k, 1),
                          "launches": int(n_k),

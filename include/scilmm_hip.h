@@ -238,6 +238,10 @@ typedef struct scilmm_timing {
   /* the dense-tail kernel alone (k_dense_b / k_dense_h / k_dense32): summed launch durations and launch count of the last factorize */
   double dense_ms;
   int64_t n_dense_launches;
+  /* multi-GPU: own tail targets of the last factorize whose late update was issued in two parts -- the sources that had
+   * already arrived first, the newest source panel's items after the wait for its broadcast (look-ahead on the chain's
+   * critical path); 0 on one GPU */
+  int64_t n_late_split;
 } scilmm_timing;
 int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out);
 /* Bracket every kernel class of the factorization with HIP events on the handle's stream (bench.py's

@@ -53,7 +53,8 @@ class Timing(C.Structure):
                 ("solve_bwd_ms", C.c_double), ("lmul_ms", C.c_double), ("quad_ms", C.c_double),
                 ("n_launches", C.c_int64), ("update_ms", C.c_double), ("potrf_ms", C.c_double),
                 ("trsm_ms", C.c_double), ("n_update_launches", C.c_int64), ("reduce_cells_ms", C.c_double),
-                ("update_union_ms", C.c_double), ("dense_ms", C.c_double), ("n_dense_launches", C.c_int64)]
+                ("update_union_ms", C.c_double), ("dense_ms", C.c_double), ("n_dense_launches", C.c_int64),
+                ("n_late_split", C.c_int64)]
 
 
 # every symbol include/scilmm_hip.h declares (tests check that the library exports all of them)

@@ -107,6 +107,7 @@ struct Dev {
   DenseWork* d_dwork_b = nullptr;       // batch items of the distributed tail
   std::vector<int64_t> dbatch_ptr;      // [ngroups+1]
   std::vector<hipEvent_t> batch_ev;     // [ngroups] batch g applied to all own targets
+  std::vector<hipEvent_t> bpev;         // profiling: [2 ngroups] begin / end of batch g on the batches' stream
   std::vector<int32_t> last_own_level;  // [ngroups] level of this rank's last own tail front in group g, or -1
   hipStream_t bstream = nullptr;        // the batches' stream
   hipStream_t comm = nullptr;           // caller-owned stream the collectives are issued on
@@ -141,6 +142,11 @@ struct Dev {
   DenseWork* d_dwork_e = nullptr;
   DenseWork* d_dwork_l = nullptr;
   std::vector<int64_t> dwork_e_ptr, dwork_l_ptr;  // [nlevels+1]
+  // distributed tail, look-ahead split of an own target's late update: items [dwork_l_ptr[l], dwork_l_mid[l]) take the sources
+  // that arrived EARLIER (they run while the newest source panel is still being factored / broadcast), items
+  // [dwork_l_mid[l], dwork_l_ptr[l+1]) the newest source alone (== dwork_l_ptr[l+1] where nothing is split)
+  std::vector<int64_t> dwork_l_mid;               // [nlevels]
+  int64_t n_late_split = 0;                       // levels of the last factorization whose late launch was split
   int look_depth = 2;      // "late" = descendants at most this many levels below the target; older ones are "early"
   int rhs_pending = -1;            // mode of the last run_rhs whose events have not been read yet
   // dense-chain sweeps (k_chain): the last chain_T levels are single fronts whose mutual update pairs are contiguous
@@ -245,6 +251,8 @@ void dev_free(void* p) {
   for (auto& e : D->done_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : D->batch_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : D->bpev)
     if (e) (void)hipEventDestroy(e);
   if (D->bstream) (void)hipStreamDestroy(D->bstream);
   delete D;
@@ -1101,6 +1109,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     std::vector<DenseWork> dwork_e, dwork_l;
     D->dwork_e_ptr.assign(S.nlevels + 1, 0);
     D->dwork_l_ptr.assign(S.nlevels + 1, 0);
+    D->dwork_l_mid.assign((size_t)std::max(S.nlevels, 1), 0);
     D->work_ptr.assign(S.nlevels + 1, 0);
     D->early_ptr.assign(S.nlevels + 1, 0);
     D->red_ptr.assign(S.nlevels + 1, 0);
@@ -1203,6 +1212,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       std::vector<std::pair<int32_t, int32_t>> segs_e, segs_l;  // descendant ranges of the level's dense items
       std::vector<uint8_t> pair_on;                             // per tile pair of the dense target: does it get items
       const int64_t dunit = 1 + (NB + KC - 1) / KC;  // cost units of one tail descendant on one tile
+      int32_t nseg_older = -1;  // look-ahead split: K segments of the level's late dense items that do NOT read the newest source
       int32_t dfr = -1;  // the tail fronts lie on a chain: at most one of them per level
       if (D->dense_on)
         for (int32_t q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q)
@@ -1290,7 +1300,20 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
             cut_runs(total, nseg, &out);
             return total;
           };
-          const int64_t act_e = dist ? 0 : build(0, dcnt_e, segs_e), act_l = build(jj - dcnt_l, jj, segs_l);
+          int64_t act_l;
+          if (dist && dcnt_l >= 2 && !(tune_env("SCILMM_DIST_NOSPLIT") && tune_env("SCILMM_DIST_NOSPLIT")[0] == '1')) {
+            // look-ahead split (multi-GPU critical path): the NEWEST source, panel jj - 1, gets K segments of its own, listed
+            // last -- the level loop launches the segments of the older sources before it waits for that panel's broadcast
+            std::vector<std::pair<int32_t, int32_t>> newest;
+            act_l = build(jj - dcnt_l, jj - 1, segs_l);
+            nseg_older = (int32_t)segs_l.size();
+            act_l += build(jj - 1, jj, newest);
+            segs_l.insert(segs_l.end(), newest.begin(), newest.end());
+            if (newest.empty()) nseg_older = -1;  // (the newest source does not reach this target: nothing to wait for separately)
+          } else {
+            act_l = build(jj - dcnt_l, jj, segs_l);
+          }
+          const int64_t act_e = dist ? 0 : build(0, dcnt_e, segs_e);
           dense_pairs_all += dist ? dcnt_l : jj;
           dense_pairs_kept += act_e + act_l;
           for (uint8_t v : pair_on) { dense_tiles_all += 1; dense_tiles_kept += v; }
@@ -1387,6 +1410,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       }
       D->dwork_e_ptr[l + 1] = (int64_t)dwork_e.size();
       D->dwork_l_ptr[l + 1] = (int64_t)dwork_l.size();
+      {
+        // (items are K-segment major: the first nseg_older segments x the active tile pairs are the older sources' items)
+        int64_t np_on_l = 0;
+        if (dj >= 0 && nseg_older >= 0)
+          for (uint8_t v : pair_on) np_on_l += v;
+        D->dwork_l_mid[(size_t)l] = (dj >= 0 && nseg_older >= 0) ? D->dwork_l_ptr[l] + (int64_t)nseg_older * np_on_l : D->dwork_l_ptr[l + 1];
+      }
       max_slots = std::max(max_slots, slots);
       D->lev_cost_e.push_back(total_e);
       D->lev_cost_l.push_back(total_l);
@@ -1804,11 +1834,17 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     HIPCHK(hipStreamWaitEvent(D->comm, D->ev_asm, 0));
   }
   const bool prof = D->profiling;
-  constexpr int PE = 12;  // profiling events per level
+  constexpr int PE = 14;  // profiling events per level
+  D->n_late_split = 0;
   if (prof && D->pev.size() < (size_t)PE * S.nlevels) {
     size_t old = D->pev.size();
     D->pev.resize((size_t)PE * S.nlevels, nullptr);
     for (size_t i = old; i < D->pev.size(); ++i) HIPCHK(hipEventCreate(&D->pev[i]));
+  }
+  if (prof && dist && D->bpev.size() < 2 * D->batch_ev.size()) {
+    size_t old = D->bpev.size();
+    D->bpev.resize(2 * D->batch_ev.size(), nullptr);
+    for (size_t i = old; i < D->bpev.size(); ++i) HIPCHK(hipEventCreate(&D->bpev[i]));
   }
   // A dispatch counts WORK-ITEMS in 32 bits: cnt workgroups of `threads` threads must stay below 2^32 of them.
   // Every launch helper below cuts its grid at max_groups(threads) workgroups (k_outside was the only
@@ -1927,13 +1963,24 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       // own tail panel: every batch up to group grp - 2 has been applied to it; its late sources -- the panels of the
       // group before and of its own group so far -- have arrived (own ones: their level event)
       if (grp >= 2) HIPCHK(hipStreamWaitEvent(st, D->batch_ev[grp - 2], 0));
-      for (int32_t q = std::max(0, (grp - 1) * Wg); q < jj; ++q) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * S.sn_level[D->dist_first + q]], 0));
+      // (look-ahead split: the wait for the NEWEST source, panel jj - 1, comes after the launch of the older sources' items)
+      const int32_t q_end = D->dwork_l_mid[(size_t)l] < D->dwork_l_ptr[l + 1] ? jj - 1 : jj;
+      for (int32_t q = std::max(0, (grp - 1) * Wg); q < q_end; ++q) HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * S.sn_level[D->dist_first + q]], 0));
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 0], st));
     if (w1 > w0) launch_update(st, D->d_work + w0, w1 - w0, sh);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 10], st));
-    launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], D->dwork_l_ptr[l + 1] - D->dwork_l_ptr[l], sh);
+    const bool split_late = tf >= 0 && D->keep_front[tf] && D->dwork_l_mid[(size_t)l] < D->dwork_l_ptr[l + 1];
+    launch_dense(st, D->d_dwork_l + D->dwork_l_ptr[l], (split_late ? D->dwork_l_mid[(size_t)l] : D->dwork_l_ptr[l + 1]) - D->dwork_l_ptr[l], sh);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 11], st));
+    if (split_late) {
+      // the older sources' items are queued (they run while panel jj - 1 is still on its way); now its arrival, then its items
+      HIPCHK(hipStreamWaitEvent(st, D->lev_ev[2 * S.sn_level[D->dist_first + jj - 1]], 0));
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 12], st));
+      launch_dense(st, D->d_dwork_l + D->dwork_l_mid[(size_t)l], D->dwork_l_ptr[l + 1] - D->dwork_l_mid[(size_t)l], sh);
+      if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 13], st));
+      D->n_late_split++;
+    }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 1], st));
     // (the late slabs are folded by k_potrf / k_trsm on load: no k_reduce launch on the main stream's chain)
     launch_cells(st, 1, l);
@@ -2010,7 +2057,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         hipStream_t bs = D->bstream;
         for (int32_t q = grp * Wg; q <= jj; ++q) HIPCHK(hipStreamWaitEvent(bs, D->lev_ev[2 * S.sn_level[D->dist_first + q]], 0));
         if (D->outside_on) HIPCHK(hipStreamWaitEvent(bs, D->out_ev, 0));
+        if (prof) HIPCHK(hipEventRecord(D->bpev[2 * (size_t)grp], bs));
         launch_dense(bs, D->d_dwork_b + D->dbatch_ptr[grp], D->dbatch_ptr[grp + 1] - D->dbatch_ptr[grp], nullptr);
+        if (prof) HIPCHK(hipEventRecord(D->bpev[2 * (size_t)grp + 1], bs));
         HIPCHK(hipEventRecord(D->batch_ev[grp], bs));
       }
     }
@@ -2080,7 +2129,7 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
   const Symbolic& S = *sym->S;
   hipStream_t st = D->stream;
   const bool prof = D->profiling;
-  constexpr int PE = 12;
+  constexpr int PE = 14;
   fac->pending = false;
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipStreamSynchronize(D->side));
@@ -2116,9 +2165,18 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
         nd++;
       }
       if (D->dwork_l_ptr[l + 1] > D->dwork_l_ptr[l]) {
-        HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 10], D->pev[PE * l + 11]));
-        td += x;
-        nd++;
+        const bool split = D->world > 1 && D->dwork_l_mid[(size_t)l] < D->dwork_l_ptr[l + 1] && D->tail_of_level[l] >= 0 &&
+                           D->keep_front[D->tail_of_level[l]];
+        if (!split || D->dwork_l_mid[(size_t)l] > D->dwork_l_ptr[l]) {
+          HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 10], D->pev[PE * l + 11]));
+          td += x;
+          nd++;
+        }
+        if (split) {  // (the newest source's items: their own bracket, so that the wait for its broadcast is not counted as kernel time)
+          HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 12], D->pev[PE * l + 13]));
+          td += x;
+          nd++;
+        }
       }
       HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 1], D->pev[PE * l + 2]));
       tmid += x;
@@ -2126,6 +2184,19 @@ int finish_factorize(scilmm_factor* fac, int32_t* bad_col) {
       tp += x;
       HIPCHK(hipEventElapsedTime(&x, D->pev[PE * l + 3], D->pev[PE * l + 4]));
       tt += x;
+    }
+    if (D->world > 1 && D->dist_first < S.nsuper && D->bpev.size() >= 2 * D->batch_ev.size()) {
+      // distributed tail: the batches (one launch sequence per complete source group, on their own stream) carry the bulk of
+      // this rank's dense-tail flops; the per-level "late" launches above the rest
+      for (size_t g = 0; g < D->batch_ev.size(); ++g) {
+        if (D->dbatch_ptr[g + 1] <= D->dbatch_ptr[g]) continue;
+        float x = 0;
+        HIPCHK(hipEventElapsedTime(&x, D->bpev[2 * g], D->bpev[2 * g + 1]));
+        td += x;
+        tu += x;
+        nd++;
+        nu++;
+      }
     }
     D->timing.update_ms = tu;       // sum of k_update launch durations (early + late; they overlap other kernels)
     D->timing.potrf_ms = tp;
@@ -3338,6 +3409,7 @@ int scilmm_last_timing(const scilmm_symbolic* sym, scilmm_timing* out) {
     if (hipEventSynchronize(D->ev[7]) == hipSuccess && hipEventElapsedTime(&q, D->ev[6], D->ev[7]) == hipSuccess) D->timing.quad_ms = q;
     D->quad_pending = false;
   }
+  D->timing.n_late_split = D->n_late_split;
   *out = D->timing;
   return SCILMM_OK;
 }

@@ -56,14 +56,17 @@ def _worker(rank, world, port, out, env):
     info = eng.sym.info()
     _, loff, params = tail_layout(eng.sym._h, info.nsuper, rank, world)
     np.savez(out % rank, nll=nll, grad=grad, logdet=ld1, X=X1, logdet2=eng.logdet(), X2=eng.solve(B), Z2=eng.lmul(B),
-             perm=eng.P(), local=loff[-1], total=info.nnzL_stored, params=np.array(params), nsuper=info.nsuper)
+             perm=eng.P(), local=loff[-1], total=info.nnzL_stored, params=np.array(params), nsuper=info.nsuper,
+             late_split=eng.sym.timing()["n_late_split"])
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,env", [(2, {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "2"}), (2, {}),
-                                       (3, {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "3", "SCILMM_OUTSIDE": "1"})],
-                         ids=["2 ranks, groups of 2 (ring re-used)", "2 ranks, default rule", "3 ranks, groups of 3, k_outside"])
+                                       (3, {"SCILMM_TUNING": "1", "SCILMM_DIST_GROUP": "3", "SCILMM_OUTSIDE": "1"}),
+                                       (2, {"SCILMM_TUNING": "1", "SCILMM_DIST_NOSPLIT": "1"})],
+                         ids=["2 ranks, groups of 2 (ring re-used)", "2 ranks, default rule", "3 ranks, groups of 3, k_outside",
+                              "2 ranks, late update in one piece"])
 def test_ranks_sharing_one_gpu_match_single_process(tmp_path, world, env):
     """24 tail panels over 2 / 3 ranks.  Groups of 2: ring of 8 slots, re-used three times, 12 batches; default: groups of
     8.  The third case also forces the atomic prelude -> tail contributions (k_outside, the 300k / 1M default) restricted
@@ -94,6 +97,12 @@ def test_ranks_sharing_one_gpu_match_single_process(tmp_path, world, env):
         assert rel_err(g["Z2"], f2.lmul(B)) < 1e-10
         first, Wg, G = (int(v) for v in g["params"])
         assert int(g["nsuper"]) - first == 24 and Wg % world == 0 and G == 4 * Wg
+        # look-ahead on the chain: an own target's late update is issued in two parts -- the sources that have arrived, then,
+        # after the wait for its broadcast, the newest source panel alone (every own target with two or more late sources)
+        if env.get("SCILMM_DIST_NOSPLIT") == "1":
+            assert int(g["late_split"]) == 0
+        else:
+            assert 24 // world - 2 <= int(g["late_split"]) <= 24 // world
 
 
 def test_distributed_tail_with_fp32_product_fronts(tmp_path):
@@ -121,6 +130,58 @@ def test_distributed_tail_with_fp32_product_fronts(tmp_path):
         assert rel_err(g["X2"], f2(B)) < 1e-5 and rel_err(g["Z2"], f2.lmul(B)) < 1e-5
     # every rank ends with the same result (to rounding: the replicated prelude sums its tail contributions with atomics)
     assert rel_err(got[0]["X"], got[1]["X"]) < 1e-12 and abs(got[0]["logdet"] - got[1]["logdet"]) < 1e-10 * abs(got[0]["logdet"])
+
+
+def _rccl_worker(rank, world, port, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from scilmm_amd.dist import DistributedEvaluator, HipChainEngine
+    mats, C, y = _problem()
+    eng = HipChainEngine(mats, rank, world, dist, "cuda:0")
+    ev = DistributedEvaluator(eng, mats, C, y, rank, world, dist, device="cuda:0", refine_steps=1)
+    np.random.seed(4)
+    nll, grad = ev.evaluate(np.log([0.45, 0.5]), reml=True, sim_num=50)
+    # the three collectives the engine's callback issues, through the SAME callback object, on RCCL: with one rank each of
+    # them must leave the data as it is (and must not fail or hang on the communication stream)
+    before = [b[:64].clone() for b in eng._bufs]
+    rc = [eng._cb(None, op, buf, 0, 64, 0) for op in (0, 1, 2) for buf in (0, 1, 2, 3)]
+    eng._comm_stream.synchronize()
+    same = all(bool(torch.equal(a, b[:64])) for a, b in zip(before, eng._bufs))
+    t = torch.ones(8, dtype=torch.float64, device="cuda:0")
+    dist.all_reduce(t)
+    dist.barrier()
+    np.savez(out % rank, nll=nll, grad=grad, rc=np.array(rc), same=same, collectives=eng.collectives, backend=dist.get_backend(),
+             refinement=np.array(ev.last_refinement), allreduce=t.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_smoke(tmp_path):
+    """The production backend at last: torch.distributed "nccl" (= RCCL) on the one GPU this box has, world size 1 -- the
+    process group of bench.py's N > 1 branch is created with device_id, a HipChainEngine + DistributedEvaluator evaluation
+    runs on top of it (device-resident, with one forced refinement sweep: its all-reduce goes through RCCL), and the engine's
+    communication callback issues broadcast / all-reduce(sum) / all-reduce(min) on device slices on its communication
+    stream.  What this cannot show: a second rank (RCCL refuses two ranks on one device) -- the multi-rank control flow is the
+    gloo tests above, the multi-GPU run the driver's."""
+    import torch.multiprocessing as mp
+    from oracle import reml_oracle as RO
+    from scilmm_amd.factor import Symbolic
+    out = str(tmp_path / "rccl%d.npz")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    g = np.load(out % 0)
+    mats, C, y = _problem()
+    np.random.seed(4)
+    nll, grad = RO.evaluate(np.log([0.45, 0.5]), mats, C, y, True, 50, perm=Symbolic(mats, upload=False).P())
+    assert str(g["backend"]) == "nccl"
+    assert abs(g["nll"] - nll) < 1e-10 * abs(nll) and rel_err(g["grad"], grad) < 1e-7
+    assert np.all(g["rc"] == 0) and bool(g["same"]) and int(g["collectives"]) == 12
+    assert g["refinement"].shape == (1,) and g["refinement"][0] < 1e-12 and np.all(g["allreduce"] == 1.0)
 
 
 def _problem_k3():
