@@ -217,6 +217,15 @@ int scilmm_dominance_dev(int32_t n, const int64_t* d_indptr, const int32_t* d_in
                          const int32_t* d_parents, double* d_out, void* stream);
 const char* scilmm_dominance_error(void);
 
+/* Y = A X for a CSR matrix (both halves stored; any square sparse matrix) and a row-major n x r block, all DEVICE pointers,
+ * enqueued on `stream` (0 = default): needs NO symbolic analysis.  The n x 100 products of the Haseman-Elston standard error
+ * (reference SparseCholesky.py:259-278 `mat_j.dot(sim_y)`, `H.dot(t)`: four per matrix pair on the host) -- HE is what the
+ * reference's authors run above 250k individuals (README.md:63) and it never factorizes.  X and Y must not alias.
+ * scilmm_csr_spmm_error(): text of the calling thread's last failure. */
+int scilmm_csr_spmm_dev(int32_t n, const int64_t* d_indptr, const int32_t* d_indices, const double* d_data, const double* d_X,
+                        int32_t r, double* d_Y, void* stream);
+const char* scilmm_csr_spmm_error(void);
+
 /* --- device-pointer variants used by bench.py and by callers that keep data resident in HBM */
 int scilmm_solve_dev(scilmm_factor* fac, const double* dB, int32_t r, double* dX);
 int scilmm_lmul_dev(scilmm_factor* fac, const double* dR, int32_t r, double* dZ);

@@ -45,6 +45,21 @@ def compute_fixed_effects_p_value(y, covariates, fixed_effects, L_CT_invV_C):
 def compute_sig_of_sig(mats, covariates, factor, y, sim_num):
     """Standard errors of the variance components (LMM.py:136-151)."""
     K = len(mats)
+    from ..SparseCholesky import _DeviceProjector, _hip_factor_of, _spmm_on_device
+    hip = _hip_factor_of(factor, mats)
+    if hip is not None:
+        # the same recursion with every n-vector in HBM: V^-1 [C | y] (one sweep), K SpMMs on P y, one K-column sweep, K SpMMs
+        # on K columns, one K^2-column sweep (the reference's form: K (K + 3) / 2 + 2 single-column host round trips)
+        torch, sym = hip
+        pr = _DeviceProjector(torch, sym, factor, covariates, y)
+        Py_d = pr.project_solved(pr.Viy[:, None])
+        inner_d = pr.solve(torch.cat([_spmm_on_device(torch, sym, j, Py_d) for j in range(K)], dim=1))      # column j = V^-1 A_j P y
+        cols = pr.solve(torch.cat([_spmm_on_device(torch, sym, i, inner_d) for i in range(K)], dim=1))      # column i K + j
+        v = (torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).cuda() @ cols).cpu().numpy().reshape(K, K)
+        hess = np.empty((K, K))
+        for i, j in combinations_with_replacement(range(K), 2):
+            hess[i, j] = hess[j, i] = -0.5 * v[i, j]
+        return np.sqrt(np.diag(la.inv(-hess) * (1 + 1.0 / sim_num)))
     V_inv_y = factor(y)
     V_inv_C = factor(covariates)
     CtViC_inv = np.linalg.inv(covariates.T.dot(V_inv_C))

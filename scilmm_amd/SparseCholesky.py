@@ -219,6 +219,49 @@ def _device_buffers():
         return None
 
 
+def _solve_on_device(torch, sym, fac, dB, sig2g_array=None):
+    """X = V^-1 B for a device block (n x r torch tensor) on the resident factor, without leaving HBM.  On a factor with
+    fp32-product fronts the solve is refined against the exact V = sum_k sigma2_k A_k (what ``Factor.__call__`` does through
+    host buffers): each sweep = K SpMMs + one more solve and gains ~7 digits."""
+    import ctypes
+    vp = ctypes.c_void_p
+    r_all = dB.shape[1]
+    dX = torch.empty_like(dB)
+    torch.cuda.synchronize()
+    fac.solve_dev(vp(dB.data_ptr()), r_all, vp(dX.data_ptr()))
+    sym.sync()
+    if getattr(sym, "front_bits", 64) == 32:
+        s2 = fac._s2 if sig2g_array is None else np.asarray(sig2g_array, dtype=float)
+        if s2 is None:
+            raise _lib.ScilmmError("refinement needs the sigma2 the resident factor was built from")
+        dY, dRes = torch.empty_like(dB), torch.empty_like(dB)
+        for _ in range(fac.REFINE_STEPS):
+            dRes.copy_(dB)
+            for k in range(len(s2)):
+                torch.cuda.synchronize()
+                sym.spmm_dev(k, vp(dX.data_ptr()), r_all, vp(dY.data_ptr()))
+                sym.sync()
+                dRes.sub_(dY, alpha=float(s2[k]))
+            torch.cuda.synchronize()
+            fac.solve_dev(vp(dRes.data_ptr()), r_all, vp(dY.data_ptr()))
+            sym.sync()
+            dX.add_(dY)
+        del dY, dRes
+        torch.cuda.synchronize()
+    return dX
+
+
+def _spmm_on_device(torch, sym, k, dX):
+    """A_k X for a device block (``scilmm_spmm_dev``)."""
+    import ctypes
+    dX = dX.contiguous()
+    dY = torch.empty_like(dX)
+    torch.cuda.synchronize()
+    sym.spmm_dev(k, ctypes.c_void_p(dX.data_ptr()), dX.shape[1], ctypes.c_void_p(dY.data_ptr()))
+    sym.sync()
+    return dY
+
+
 def _finish_on_device(torch, sym, fac, R, sig2g_array, covariates, y, reml, sim_num):
     """Everything after the factorization of one evaluation with the n x 100 blocks kept in HBM: R goes down once,
     Z = P^T L R, the 103-column solve and the K fused SpMM + reduce calls read and write device buffers through the
@@ -236,29 +279,8 @@ def _finish_on_device(torch, sym, fac, R, sig2g_array, covariates, y, reml, sim_
     head = torch.from_numpy(np.ascontiguousarray(np.hstack([covariates, y[:, None]]))).cuda()
     dB = torch.cat([head, dZ], dim=1).contiguous()
     del dZ
-    dX = torch.empty_like(dB)
-    torch.cuda.synchronize()
-    fac.solve_dev(vp(dB.data_ptr()), c + 1 + sim_num, vp(dX.data_ptr()))
-    sym.sync()
-    if getattr(sym, "front_bits", 64) == 32:
-        # fp32-product fronts: the factor carries a ~1e-7 backward error; the solve is refined against the exact
-        # V = sum_k sigma2_k A_k without leaving the device (what Factor.__call__ does through host buffers): each sweep
-        # = K SpMMs + one more solve on the resident factor and gains ~7 digits
-        r_all = c + 1 + sim_num
-        dY, dRes = torch.empty_like(dB), torch.empty_like(dB)
-        for _ in range(fac.REFINE_STEPS):
-            dRes.copy_(dB)
-            for k in range(len(sig2g_array)):
-                torch.cuda.synchronize()
-                sym.spmm_dev(k, vp(dX.data_ptr()), r_all, vp(dY.data_ptr()))
-                sym.sync()
-                dRes.sub_(dY, alpha=float(sig2g_array[k]))
-            torch.cuda.synchronize()
-            fac.solve_dev(vp(dRes.data_ptr()), r_all, vp(dY.data_ptr()))
-            sym.sync()
-            dX.add_(dY)
-        del dY, dRes
-        torch.cuda.synchronize()
+    # (fp32-product fronts: refined against the exact V on the device, see _solve_on_device)
+    dX = _solve_on_device(torch, sym, fac, dB, sig2g_array)
     del dB
     Xh = dX[:, :c + 1].cpu().numpy()
     invV_C, invV_y0 = Xh[:, :c], Xh[:, c]
@@ -497,6 +519,15 @@ def _ai_reml(cholesky_func, mats, covariates, y, x0, reml, sim_num, verbose, max
 
     def information(fac):
         # P y and P A_k P y through the resident factor: 1 + K multi-column solves
+        hip = _hip_factor_of(fac, mats)
+        if hip is not None:
+            # ... in HBM: V^-1 [C | y] (one sweep), K SpMMs on one column, one K-column sweep
+            torch, sym = hip
+            pr = _DeviceProjector(torch, sym, fac, covariates, y)
+            Py_d = pr.project_solved(pr.Viy[:, None])
+            APy_d = torch.cat([_spmm_on_device(torch, sym, k, Py_d) for k in range(len(mats))], dim=1)
+            AI_d = 0.5 * (APy_d.T @ pr.project(APy_d)).cpu().numpy()
+            return 0.5 * (AI_d + AI_d.T)
         ViC = fac(covariates)
         G = la.cho_factor(covariates.T.dot(ViC))
 
@@ -589,8 +620,74 @@ def _final_factor(cholesky_func, mats, coefficients):
     return cholesky_func(matrices_weighted_sum(mats, coefficients))
 
 
+def _hip_factor_of(factor, mats):
+    """(torch, symbolic) when ``factor`` is a resident HIP factor of exactly these matrices and device buffers are available
+    -- the post-fit algebra then runs as a few multi-column device sweeps -- else None (the reference-shaped host loops)."""
+    from .factor import Factor
+    if not isinstance(factor, Factor) or getattr(factor, "_s2", None) is None:
+        return None
+    sym = factor.sym
+    if factor._epoch != sym._values_epoch:   # (the resident values changed after this factorization)
+        return None
+    if len(mats) != sym.K or any(m.shape != (sym.n, sym.n) or m.nnz != sym._indices[k].size for k, m in enumerate(mats)):
+        return None
+    torch = _device_buffers()
+    return None if torch is None else (torch, sym)
+
+
+class _DeviceProjector(object):
+    """P z = V^-1 z - V^-1 C (C' V^-1 C)^-1 C' V^-1 z on device blocks (SparseCholesky.py:153-155), with V^-1 [C | y] from
+    ONE multi-column sweep of the resident factor."""
+
+    def __init__(self, torch, sym, factor, covariates, y):
+        self.torch, self.sym, self.factor = torch, sym, factor
+        self.c = c = covariates.shape[1]
+        self.dC = torch.from_numpy(np.ascontiguousarray(covariates, dtype=np.float64)).cuda()
+        dB = torch.cat([self.dC, torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)[:, None]).cuda()], dim=1).contiguous()
+        dX = _solve_on_device(torch, sym, factor, dB)
+        self.ViC, self.Viy = dX[:, :c].contiguous(), dX[:, c].contiguous()
+        self.CtViC = (self.dC.T @ self.ViC).cpu().numpy()          # c x c: host LAPACK, like the reference
+        self.L_CT_Vinv_C = la.cho_factor(self.CtViC)
+
+    def solve(self, dZ):
+        return _solve_on_device(self.torch, self.sym, self.factor, dZ.contiguous())
+
+    def project_solved(self, ViZ):
+        """P Z given V^-1 Z."""
+        coef = la.cho_solve(self.L_CT_Vinv_C, (self.dC.T @ ViZ).cpu().numpy())
+        return ViZ - self.ViC @ self.torch.from_numpy(np.ascontiguousarray(coef)).to(ViZ.device)
+
+    def project(self, dZ):
+        return self.project_solved(self.solve(dZ))
+
+
+def _compute_hess_device(torch, sym, mats, covariates, factor, y, proj=None):
+    """compute_hess with every n-vector in HBM: V^-1 [C | y] (one sweep), A_j P y for all j (K SpMMs on one column), their
+    projection (one K-column sweep), A_i (P A_j P y) for all i, j (K SpMMs on K columns), their projection (one K^2-column
+    sweep) and K^2 dot products with y -- 3 sweeps and 2 K SpMM calls instead of 2 + K + K (K + 1) / 2 single-column sweeps
+    and as many host SciPy products with PCIe round trips (SparseCholesky.py:147-168; 56 s of the 239 s 1M fit in round 3)."""
+    K = len(mats)
+    proj = proj or _DeviceProjector(torch, sym, factor, covariates, y)
+    dy = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).cuda()
+    Py = proj.project_solved(proj.Viy[:, None])                                               # n x 1
+    APy = torch.cat([_spmm_on_device(torch, sym, j, Py) for j in range(K)], dim=1)            # n x K: column j = A_j P y
+    PAPy = proj.project(APy)                                                                  # n x K: column j = P A_j P y
+    cols = torch.cat([_spmm_on_device(torch, sym, i, PAPy) for i in range(K)], dim=1)         # n x K^2: column i K + j = A_i P A_j P y
+    Pcols = proj.project(cols)
+    v = (dy @ Pcols).cpu().numpy().reshape(K, K)                                              # v[i, j] = y' P A_i P A_j P y
+    hess = np.empty((K, K))
+    for j in range(K):
+        for i in range(j + 1):
+            hess[i, j] = hess[j, i] = -0.5 * v[i, j]
+    return hess
+
+
 def compute_hess(mats, covariates, factor, y):
-    """AI-style Hessian of the log-likelihood by projected solves (SparseCholesky.py:147-168)."""
+    """AI-style Hessian of the log-likelihood by projected solves (SparseCholesky.py:147-168).  On a resident HIP factor
+    the same quantities are computed by a few multi-column device sweeps (``_compute_hess_device``)."""
+    hip = _hip_factor_of(factor, mats)
+    if hip is not None:
+        return _compute_hess_device(hip[0], hip[1], mats, covariates, factor, y)
     K = len(mats)
     Vinv_C = factor(covariates)
     L_CT_Vinv_C = la.cho_factor(covariates.T.dot(Vinv_C))
@@ -621,8 +718,17 @@ def REML(cholesky_func, mats, covariates, y, reml=True, sim_num=100, verbose=Fal
     mats = list(mats) + [sparse.eye(y.shape[0]).tocsr()]
     varcomp_estimates = estimate_var_comps(cholesky_func, mats, covariates, y, reml, sim_num, verbose, aireml=aireml)
     factor = _final_factor(cholesky_func, mats, varcomp_estimates)
-    _, _, _, fixed_effects = estimate_fixed_effects(factor, y, covariates)
-    sigmas_sigmas = compute_varcomp_stderr(mats, covariates, factor, y, sim_num)
+    hip = _hip_factor_of(factor, mats)
+    if hip is not None:
+        # everything after the fit from ONE V^-1 [C | y] sweep + the two sweeps of the Hessian, all in HBM
+        proj = _DeviceProjector(hip[0], hip[1], factor, covariates, y)
+        fixed_effects = la.cho_solve(proj.L_CT_Vinv_C, (proj.dC.T @ proj.Viy).cpu().numpy())
+        hess = _compute_hess_device(hip[0], hip[1], mats, covariates, factor, y, proj=proj)
+        sigmas_sigmas = np.sqrt(np.diag(la.inv(-hess)) * (1 + 1.0 / sim_num))
+        del proj
+    else:
+        _, _, _, fixed_effects = estimate_fixed_effects(factor, y, covariates)
+        sigmas_sigmas = compute_varcomp_stderr(mats, covariates, factor, y, sim_num)
     del factor
     if _is_hip(cholesky_func):
         cholesky_func.release_factors()
@@ -690,7 +796,30 @@ def HE(mat_list, cov, y, MQS=False, verbose=False, sim_num=100, compute_stderr=F
         H = H + mat_k * sigma2_k
     H = H + sparse.eye(n, format='csr') * (1.0 - he_est.sum())
     V_q = np.empty((K, K))
-    for i, mat_i in enumerate(mat_list):
+    torch = _device_buffers() if (sim_num is not None and all(sparse.issparse(m) for m in mat_list)) else None
+    if torch is not None:
+        # the Monte-Carlo variance (:259-278) with the n x sim_num blocks in HBM: every product is one pass of
+        # scilmm_csr_spmm_dev over a device-resident copy of the matrix (no symbolic analysis: HE never factorizes); the
+        # normal blocks come from the same np.random stream, pair by pair, as on the host
+        dmats = [_lib.DeviceCSR(m, torch) for m in mat_list]
+        rest = 1.0 - float(he_est.sum())
+
+        def H_dot(t):
+            out = t * rest
+            for dm, s2k in zip(dmats, he_est):
+                out.add_(dm.dot(t), alpha=float(s2k))
+            return out
+
+        for i in range(K):
+            for j in range(i + 1):
+                d_sim = torch.from_numpy(np.random.randn(n, sim_num)).cuda()
+                t = dmats[j].dot(d_sim).sub_(d_sim)
+                t = H_dot(t)
+                t = dmats[i].dot(t).sub_(t)
+                t = H_dot(t)
+                V_q[i, j] = V_q[j, i] = 2.0 * float((d_sim * t).sum(dim=0).mean())
+        del dmats
+    for i, mat_i in enumerate(mat_list if torch is None else []):
         for j, mat_j in enumerate(mat_list[:i + 1]):
             if sim_num is None:
                 HAi = H.dot(mat_i) - H

@@ -71,6 +71,7 @@ SYMBOLS = [
     "scilmm_selected_inverse", "scilmm_inverse_traces",
     "scilmm_mm_read", "scilmm_mm_export", "scilmm_mm_error", "scilmm_mm_free",
     "scilmm_dominance", "scilmm_dominance_dev", "scilmm_dominance_error",
+    "scilmm_csr_spmm_dev", "scilmm_csr_spmm_error",
 ]
 
 _lib = None
@@ -153,6 +154,8 @@ def lib():
     L.scilmm_dominance.argtypes = [i32, vp, vp, vp, vp, vp]
     L.scilmm_dominance_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.scilmm_dominance_error.restype = C.c_char_p
+    L.scilmm_csr_spmm_dev.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp]
+    L.scilmm_csr_spmm_error.restype = C.c_char_p
     L.scilmm_order.argtypes = [i32, vp, vp, i32, vp]
     L.scilmm_fill_count.argtypes = [i32, vp, vp, vp, P(i64), P(dbl), P(i32)]
     _lib = L
@@ -252,3 +255,30 @@ def dominance(A, parents):
     if st != OK:
         raise ScilmmError("scilmm_dominance failed (%d): %s" % (st, (lib().scilmm_dominance_error() or b"").decode()))
     return sp.csr_matrix((out, A.indices.copy(), A.indptr.copy()), shape=A.shape)
+
+
+class DeviceCSR(object):
+    """A scipy CSR matrix resident in HBM (torch tensors: device memory only) with ``dot(dX)`` = A X for device blocks through
+    ``scilmm_csr_spmm_dev`` -- no symbolic analysis involved.  Raises when the GPU cannot be reached: there is no CPU form."""
+
+    def __init__(self, A, torch):
+        A = A.tocsr()
+        self.torch, self.n = torch, A.shape[0]
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("square matrix expected")
+        self.indptr = torch.from_numpy(np.ascontiguousarray(A.indptr, dtype=np.int64)).cuda()
+        self.indices = torch.from_numpy(np.ascontiguousarray(A.indices, dtype=np.int32)).cuda()
+        self.data = torch.from_numpy(np.ascontiguousarray(A.data, dtype=np.float64)).cuda()
+
+    def dot(self, dX):
+        torch = self.torch
+        dX = dX.contiguous()
+        if dX.dtype != torch.float64 or dX.dim() != 2 or dX.shape[0] != self.n:
+            raise ValueError("an n x r float64 device block is expected")
+        dY = torch.empty_like(dX)
+        vp = C.c_void_p
+        st = lib().scilmm_csr_spmm_dev(self.n, vp(self.indptr.data_ptr()), vp(self.indices.data_ptr()), vp(self.data.data_ptr()),
+                                       vp(dX.data_ptr()), dX.shape[1], vp(dY.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
+        if st != OK:
+            raise ScilmmError("scilmm_csr_spmm_dev failed (%d): %s" % (st, (lib().scilmm_csr_spmm_error() or b"").decode()))
+        return dY

@@ -308,6 +308,74 @@ def test_device_resident_evaluation_equals_host_buffer_path(monkeypatch, bits):
     assert rel_err(out[True][1], out[False][1]) < (1e-10 if bits == 64 else 1e-8)
 
 
+@pytest.mark.parametrize("bits", [64, 32])
+def test_post_fit_algebra_on_the_device_equals_the_reference_shaped_loops(monkeypatch, bits):
+    """`compute_hess` (SparseCholesky.py:147-168), `compute_sig_of_sig` (Estimation/LMM.py:136-151) and the
+    AI-REML information matrix as a few multi-column device sweeps + SpMMs in HBM, against the reference-shaped loops of
+    single-column solves and SciPy products on the SAME resident factor (SCILMM_HOST_BUFFERS=1 selects them): 1e-10 (fp64);
+    with fp32-product fronts both forms refine their solves against the exact V: 1e-8."""
+    from scilmm_amd.harness import pedigree as H
+    monkeypatch.setenv("SCILMM_TUNING", "1")
+    monkeypatch.setenv("SCILMM_DENSE", "1")
+    mats, C, y = H.make_problem(10000, 0.01, seed=2, with_dominance="device")
+    n = y.size
+    mats = list(mats) + [sp.identity(n, format="csr")]
+    C3 = np.hstack([np.ones((n, 1)), C[:, :1], np.random.default_rng(5).standard_normal((n, 1))])
+    chol = P.SparseCholesky(front_bits=bits)
+    sym = chol.engine_for(mats)
+    fac = sym.factorize([0.3, 0.15, 0.5])
+    out = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("SCILMM_HOST_BUFFERS", "1")
+        else:
+            monkeypatch.delenv("SCILMM_HOST_BUFFERS", raising=False)
+        assert (P._hip_factor_of(fac, mats) is None) == host
+        out[host] = (P.compute_hess(mats, C3, fac, y), P.compute_varcomp_stderr(mats, C3, fac, y, 100),
+                     M.compute_sig_of_sig(mats, C3, fac, y, 100))
+    tol = 1e-10 if bits == 64 else 1e-8
+    for a, b in zip(out[False], out[True]):
+        assert rel_err(a, b) < tol
+    assert np.allclose(out[False][0], out[False][0].T) and np.all(np.linalg.eigvalsh(-out[False][0]) > 0)
+    # a factor of OTHER matrices (or one whose values changed since) never takes the device shortcut
+    assert P._hip_factor_of(fac, mats[:2]) is None
+    sym.set_values(0, mats[0].data * 1.0)
+    assert P._hip_factor_of(fac, mats) is None
+
+
+def test_he_standard_error_products_on_the_device(monkeypatch):
+    """the Monte-Carlo standard error of HE (SparseCholesky.py:259-278; `run_estimates(reml=False)`, the
+    branch the reference's authors prefer above 250k) with its n x 100 products on the device (`scilmm_csr_spmm_dev`, no
+    symbolic analysis) against the host SciPy products with the same np.random stream -- K = 1 and K = 2; and the kernel
+    itself against scipy on ragged rows (empty rows, a row longer than a wave's 64-entry batch, r = 1 / 100 / 130)."""
+    import torch
+    from scilmm_amd import _lib
+    from scilmm_amd.harness import pedigree as H
+    mats, C, y = H.make_problem(10000, 0.01, seed=2, with_dominance="device")
+    for ms in (mats[:1], mats):
+        out = {}
+        for host in (False, True):
+            if host:
+                monkeypatch.setenv("SCILMM_HOST_BUFFERS", "1")
+            else:
+                monkeypatch.delenv("SCILMM_HOST_BUFFERS", raising=False)
+            np.random.seed(11)
+            out[host] = P.HE(ms, C, y, compute_stderr=True)
+        assert rel_err(out[False][0], out[True][0]) < 1e-12 and rel_err(out[False][1], out[True][1]) < 1e-10
+    rng = np.random.default_rng(3)
+    A = sp.random(700, 700, density=0.02, random_state=4, format="lil")
+    A[5, :] = rng.standard_normal(700)      # one full row (11 batches of 64)
+    A[9, :] = 0.0                           # ... and an empty one
+    A = A.tocsr()
+    dA = _lib.DeviceCSR(A, torch)
+    for r in (1, 100, 130):
+        X = rng.standard_normal((700, r))
+        Y = dA.dot(torch.from_numpy(X).cuda()).cpu().numpy()
+        assert rel_err(Y, A @ X) < 1e-13
+    with pytest.raises(ValueError):
+        dA.dot(torch.zeros(3, 2, dtype=torch.float64, device="cuda"))
+
+
 def test_selected_inverse_traces_at_100k_against_identity_solves():
     """The selected inverse at BASELINE configs[1]'s size (100k individuals, K = 2; 1.7 TFLOP factor, 3.4 TFLOP inversion):
     tr(V^-1 A) and tr(V^-1) against the brute-force form (163 multi-column sweeps of the factor, 55 GB over PCIe) to 1e-8,
