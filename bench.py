@@ -619,7 +619,7 @@ def main():
         # (a --pmc pass of the 1M workload does not finish inside the pool's per-call limit -- counter collection
         # serialises the 8000 launches of a factorization; the 300k pass is on file: profiles/r2_traffic_300k.json)
         traffic, traffic_src = None, None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%d_traffic_%s.json" % (rr, args.workload)) for rr in (3, 2))
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%d_traffic_%s.json" % (rr, args.workload)) for rr in (4, 3, 2))
                       if os.path.exists(q)), "")
         if tpath:
             # HBM bytes of the update kernel from a separate rocprofv3 --pmc pass of this workload (a PMC pass cannot
