@@ -135,7 +135,13 @@ struct Dev {
   int32_t* d_tail_front = nullptr;
   uint8_t* d_keep_front = nullptr;
   hipStream_t outside_st = nullptr;
-  hipEvent_t out_ev = nullptr;
+  // PROGRESSIVE k_outside: the items are sorted by the FIRST tail panel they touch and cut into chunks; chunk g is one launch
+  // and one event, and whatever touches tail panel f (its early / late updates, its potrf) waits only for the last chunk that
+  // holds an item reaching f or an earlier panel -- left-looking updates write nothing but the level's own panel, so the rest
+  // of the atomic contributions (to LATER panels only) overlaps with the first levels of the tail, which are chain-bound
+  std::vector<int64_t> ochunk_ptr;       // [nchunks + 1] into d_owork
+  std::vector<hipEvent_t> out_evs;       // [nchunks]
+  std::vector<int32_t> out_wait_chunk;   // [nlevels] chunk the level's tail front waits for, -1: none
   bool dense_on = false;
   int front_bits = 64;                  // 32: dense-tail products on the fp32 matrix pipe (k_dense32), sums in fp64
   double* d_zeros = nullptr;            // 2 KiB of zeros: source of the B k-rows past a descendant's end (k_dense_b)
@@ -245,7 +251,8 @@ void dev_free(void* p) {
   if (D->side2) (void)hipStreamDestroy(D->side2);
   if (D->side3) (void)hipStreamDestroy(D->side3);
   if (D->outside_st) (void)hipStreamDestroy(D->outside_st);
-  if (D->out_ev) (void)hipEventDestroy(D->out_ev);
+  for (auto& e : D->out_evs)
+    if (e) (void)hipEventDestroy(e);
   if (D->h_chain_err) (void)hipHostFree(D->h_chain_err);
   if (D->stream) (void)hipStreamDestroy(D->stream);
   for (auto& e : D->done_ev)
@@ -686,16 +693,62 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         D->outside_on = false;
         std::fill(D->outside_desc.begin(), D->outside_desc.end(), 0);
       } else {
-        // widest descendants first (their block pairs are the long items... all items are 128 x 128 x w_d: order by w_d)
-        std::stable_sort(ow.begin(), ow.end(), [&](const OutsideWork& a, const OutsideWork& b) {
-          return (S.sn_start[a.d + 1] - S.sn_start[a.d]) > (S.sn_start[b.d + 1] - S.sn_start[b.d]);
-        });
-        const OutsideWork* dow;
-        if ((st = upload(sym, D, ow, &dow)) != SCILMM_OK) return st;
-        D->d_owork = (OutsideWork*)dow;
         std::vector<int32_t> tf((size_t)(S.n - c0_tail));
         for (int32_t f = S.dense_first; f < S.nsuper; ++f)
           for (int32_t c = S.sn_start[f]; c < S.sn_start[f + 1]; ++c) tf[(size_t)(c - c0_tail)] = f;
+        // first tail panel an item touches = the panel of its smallest column label (first row of block bj)
+        auto first_front = [&](const OutsideWork& w) -> int32_t {
+          return tf[(size_t)(S.sn_rows[S.sn_rowptr[w.d] + w.t0 + NB * w.bj] - c0_tail)];
+        };
+        const char* ech = tune_env("SCILMM_OUTSIDE_CHUNKS");
+        // (100k / 300k factorization, ms: 1 chunk 57.8 / 1357; 4 / 8 / 16 chunks on a low-priority stream 55.5 / 1344, - / 1339, 56.1 / 1335)
+        const int32_t want_chunks = std::max(1, ech ? atoi(ech) : 8);
+        std::vector<int32_t> ffront(ow.size());
+        for (size_t i = 0; i < ow.size(); ++i) ffront[i] = first_front(ow[i]);
+        std::vector<size_t> ord(ow.size());
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return ffront[a] < ffront[b]; });
+        // chunk boundaries where the first panel changes, about equal item counts
+        D->ochunk_ptr.assign(1, 0);
+        std::vector<int32_t> chunk_lo;  // first panel of the chunk's first item
+        {
+          const size_t N = ord.size(), per = std::max<size_t>(1, (N + want_chunks - 1) / want_chunks);
+          size_t i = 0;
+          while (i < N) {
+            chunk_lo.push_back(ffront[ord[i]]);
+            size_t e = std::min(N, i + per);
+            while (e < N && ffront[ord[e]] == ffront[ord[e - 1]]) ++e;
+            D->ochunk_ptr.push_back((int64_t)e);
+            i = e;
+          }
+        }
+        const int32_t nch = (int32_t)chunk_lo.size();
+        // inside a chunk: widest descendants first (all items are 128 x 128 x w_d: the long ones start early)
+        {
+          std::vector<OutsideWork> sorted(ow.size());
+          for (int32_t g = 0; g < nch; ++g) {
+            std::stable_sort(ord.begin() + D->ochunk_ptr[g], ord.begin() + D->ochunk_ptr[g + 1], [&](size_t a, size_t b) {
+              return (S.sn_start[ow[a].d + 1] - S.sn_start[ow[a].d]) > (S.sn_start[ow[b].d + 1] - S.sn_start[ow[b].d]);
+            });
+          }
+          for (size_t i = 0; i < ord.size(); ++i) sorted[i] = ow[ord[i]];
+          ow.swap(sorted);
+        }
+        // per level: the chunk its tail front waits for = the last chunk whose first item starts at that panel or before it
+        D->out_wait_chunk.assign((size_t)std::max(S.nlevels, 1), -1);
+        for (int32_t f = S.dense_first; f < S.nsuper; ++f) {
+          const int32_t g = (int32_t)(std::upper_bound(chunk_lo.begin(), chunk_lo.end(), f) - chunk_lo.begin()) - 1;
+          int32_t& w = D->out_wait_chunk[(size_t)S.sn_level[f]];
+          w = std::max(w, g);
+        }
+        // (a level at or above the tail's first one without a tail front of its own waits like the level before it)
+        for (int32_t l = D->tail_level + 1; l < S.nlevels; ++l)
+          D->out_wait_chunk[(size_t)l] = std::max(D->out_wait_chunk[(size_t)l], D->out_wait_chunk[(size_t)l - 1]);
+        D->out_evs.assign((size_t)nch, nullptr);
+        for (auto& e : D->out_evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const OutsideWork* dow;
+        if ((st = upload(sym, D, ow, &dow)) != SCILMM_OK) return st;
+        D->d_owork = (OutsideWork*)dow;
         const int32_t* dtf;
         if ((st = upload(sym, D, tf, &dtf)) != SCILMM_OK) return st;
         D->d_tail_front = (int32_t*)dtf;
@@ -704,11 +757,18 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         D->d_keep_front = (uint8_t*)dkf;
         int lo4 = 0, hi4 = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo4, &hi4));
-        HIPCHK(hipStreamCreateWithPriority(&D->outside_st, hipStreamNonBlocking, hi4));
-        HIPCHK(hipEventCreateWithFlags(&D->out_ev, hipEventDisableTiming));
-        if (pverb)
-          fprintf(stderr, "[scilmm plan] k_outside: %lld block-pair items of prelude fronts below level %d (tail starts at column %d)\n",
-                  (long long)D->n_owork, D->tail_level, c0_tail);
+        {
+          const char* epr = tune_env("SCILMM_OUTSIDE_PRIO");  // 1: the chain's priority, 0: the look-ahead streams'
+          // (low: the chunks that later panels wait for fill the gaps of the chain-bound first tail levels instead of taking
+          //  the chain's CU slots -- with the chain's priority the overlap gains nothing)
+          HIPCHK(hipStreamCreateWithPriority(&D->outside_st, hipStreamNonBlocking, (epr && epr[0] == '1') ? hi4 : lo4));
+        }
+        if (pverb) {
+          fprintf(stderr, "[scilmm plan] k_outside: %lld block-pair items of prelude fronts below level %d (tail starts at column %d), %d chunks by first panel:",
+                  (long long)D->n_owork, D->tail_level, c0_tail, nch);
+          for (int32_t g = 0; g < nch; ++g) fprintf(stderr, " [%d..: %lld]", chunk_lo[g] - S.dense_first, (long long)(D->ochunk_ptr[g + 1] - D->ochunk_ptr[g]));
+          fprintf(stderr, "\n");
+        }
       }
     }
   }
@@ -1282,6 +1342,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
             }
             return cnt;
           };
+          bool taper = false;
           auto build = [&](int32_t lo, int32_t hi, std::vector<std::pair<int32_t, int32_t>>& out) -> int64_t {
             out.clear();
             const int64_t total = active_runs(jj, lo, hi, runs);
@@ -1298,6 +1359,23 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
               }
             }
             cut_runs(total, nseg, &out);
+            // TAPER (long launches only): the items of a launch start in list order, K-segment major, and last about as long as
+            // their segment is deep -- with equal segments the chip idles at the end of a launch while the last round of
+            // workgroups finishes (measured ~8 % of a serialised 9.8 ms launch at 1M).  The second-to-last segment is therefore
+            // cut in two and the last one in four: the launch ends on quarter-length items (a few more partial slabs per tile).
+            if (taper && out.size() >= 3) {
+              std::vector<std::pair<int32_t, int32_t>> tp(out.begin(), out.end() - 2);
+              auto split = [&](std::pair<int32_t, int32_t> sgm, int parts) {
+                const int32_t len = sgm.second - sgm.first;
+                for (int q = 0; q < parts; ++q) {
+                  const int32_t a = sgm.first + (int32_t)((int64_t)len * q / parts), b = sgm.first + (int32_t)((int64_t)len * (q + 1) / parts);
+                  if (b > a) tp.push_back({a, b});
+                }
+              };
+              split(out[out.size() - 2], 2);
+              split(out[out.size() - 1], 4);
+              out.swap(tp);
+            }
             return total;
           };
           int64_t act_l;
@@ -1313,7 +1391,11 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           } else {
             act_l = build(jj - dcnt_l, jj, segs_l);
           }
+          // (the early launch of a long tail: 1024-item launches, several rounds of workgroups)
+          const char* etp = tune_env("SCILMM_DENSE_TAPER");
+          taper = etp ? etp[0] == '1' : dense_items >= 1024;
           const int64_t act_e = dist ? 0 : build(0, dcnt_e, segs_e);
+          taper = false;
           dense_pairs_all += dist ? dcnt_l : jj;
           dense_pairs_kept += act_e + act_l;
           for (uint8_t v : pair_on) { dense_tiles_all += 1; dense_tiles_kept += v; }
@@ -1922,7 +2004,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     if (l >= D->look_depth + 1) HIPCHK(hipStreamWaitEvent(sd, D->lev_ev[2 * (l - D->look_depth - 1)], 0));
     // tail targets: the atomic contributions of the prelude (k_outside) must have landed before anything else
     // reads-modifies-writes a tail panel (the event has been recorded: these launches are deferred until it is)
-    if (D->outside_on && l >= D->tail_level) HIPCHK(hipStreamWaitEvent(sd, D->out_ev, 0));
+    if (D->outside_on && l >= D->tail_level && D->out_wait_chunk[(size_t)l] >= 0)
+      HIPCHK(hipStreamWaitEvent(sd, D->out_evs[(size_t)D->out_wait_chunk[(size_t)l]], 0));
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 5], sd));
     if (e1 > e0) launch_update(sd, D->d_work_early + e0, e1 - e0, D->scratch + (size_t)sidx * half);
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 8], sd));
@@ -1954,7 +2037,10 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       int rc = launch_early(l + D->look_depth);
       if (rc != SCILMM_OK) return rc;
     }
-    if (D->outside_on && l == D->tail_level) HIPCHK(hipStreamWaitEvent(st, D->out_ev, 0));
+    // (progressive k_outside: this level's tail panel needs the chunks that reach it, not the whole launch sequence)
+    if (D->outside_on && l >= D->tail_level && D->out_wait_chunk[(size_t)l] >= 0 &&
+        (l == D->tail_level || D->out_wait_chunk[(size_t)l] != D->out_wait_chunk[(size_t)l - 1]))
+      HIPCHK(hipStreamWaitEvent(st, D->out_evs[(size_t)D->out_wait_chunk[(size_t)l]], 0));
     const int64_t w0 = D->work_ptr[l], w1 = D->work_ptr[l + 1];
     const int32_t tf = dist ? D->tail_of_level[l] : -1;  // the distributed front of this level
     const int32_t jj = tf >= 0 ? tf - D->dist_first : -1, grp = tf >= 0 ? jj / Wg : -1;
@@ -2056,7 +2142,7 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         // ---- source group grp is complete on this rank: its batch (every own target at least two groups ahead)
         hipStream_t bs = D->bstream;
         for (int32_t q = grp * Wg; q <= jj; ++q) HIPCHK(hipStreamWaitEvent(bs, D->lev_ev[2 * S.sn_level[D->dist_first + q]], 0));
-        if (D->outside_on) HIPCHK(hipStreamWaitEvent(bs, D->out_ev, 0));
+        if (D->outside_on) HIPCHK(hipStreamWaitEvent(bs, D->out_evs.back(), 0));  // (a batch writes targets up to the last panel)
         if (prof) HIPCHK(hipEventRecord(D->bpev[2 * (size_t)grp], bs));
         launch_dense(bs, D->d_dwork_b + D->dbatch_ptr[grp], D->dbatch_ptr[grp + 1] - D->dbatch_ptr[grp], nullptr);
         if (prof) HIPCHK(hipEventRecord(D->bpev[2 * (size_t)grp + 1], bs));
@@ -2067,8 +2153,9 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
       // ---- every prelude front below the tail's first level is final: its contribution to the tail, in ITS
       //      coordinates, with atomic subtraction (k_outside); nothing else touches a tail panel meanwhile
       HIPCHK(hipStreamWaitEvent(D->outside_st, D->lev_ev[2 * l], 0));
-      for (int64_t o0 = 0; o0 < D->n_owork; o0 += max_groups(256)) {
-        const unsigned cnt = (unsigned)std::min<int64_t>(max_groups(256), D->n_owork - o0);
+      for (size_t og = 0; og + 1 < D->ochunk_ptr.size(); ++og) {
+      for (int64_t o0 = D->ochunk_ptr[og]; o0 < D->ochunk_ptr[og + 1]; o0 += max_groups(256)) {
+        const unsigned cnt = (unsigned)std::min<int64_t>(max_groups(256), D->ochunk_ptr[og + 1] - o0);
         const OutsideWork* ow = (const OutsideWork*)D->d_owork + o0;
 #ifdef SCILMM_DIAG
         if (D->ablate == 6)  // timing ablations: no scatter / plain stores (WRONG numbers)
@@ -2088,7 +2175,8 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
         HIPCHK(hipGetLastError());
         launches++;
       }
-      HIPCHK(hipEventRecord(D->out_ev, D->outside_st));
+      HIPCHK(hipEventRecord(D->out_evs[og], D->outside_st));
+      }
       for (int32_t le = D->tail_level; le <= l + D->look_depth && le < S.nlevels; ++le) {
         if (le < 1) continue;
         int rc = launch_early(le);
