@@ -468,9 +468,14 @@ def main():
         del Apat, mats_e
     t_sym = time.time() - t0
     info = sym.info()
+    # The timed steps run WITHOUT the engine's HIP-event brackets (14 timed events per level: 4 - 5 ms of a 52 ms factorization at
+    # the 100k config, tools/enqueue_time.py); the per-class figures of the line come from ONE extra, untimed evaluation with the
+    # brackets on, the clean per-launch figure from one more with the look-ahead launches serialised.  --serialised: every
+    # evaluation in mode 2 (a measurement mode); --no-engine-profiling: no bracketed evaluation at all.
     prof_mode = 0 if args.no_engine_profiling else (2 if args.serialised else 1)
-    if prof_mode:
-        sym.set_profiling(prof_mode)
+    timed_mode = 2 if args.serialised else 0
+    if timed_mode:
+        sym.set_profiling(timed_mode)
     if args.no_engine_profiling or args.serialised:
         args.no_clean_profile = True
     if args.front_bits == 32:
@@ -554,6 +559,8 @@ def main():
     reserve = CPU_BASELINE_RESERVE_S if want_cpu else 0.0
     if world == 1 and not args.no_clean_profile:
         reserve += 1.25 * t_step_est  # the serialised profiling evaluation after the timed region
+    if prof_mode == 1:
+        reserve += 1.1 * t_step_est   # the bracketed evaluation (per-class figures) after the timed region
     remaining = args.budget_s - (time.time() - T_PROCESS_START) - reserve - 10.0
     afford = int(remaining / max(t_step_est, 1e-9))
     steps = max(1, min(args.steps, afford))
@@ -591,6 +598,18 @@ def main():
         hbm_used = float(hmax[0])
     nnzL_total = float(info.nnzL)  # ONE cohort, whatever the number of ranks
     logdet_total = logdets[-1]
+    bracketed_factor_ms = None
+    if prof_mode == 1:
+        # ONE more, untimed evaluation under the default schedule with the kernel classes bracketed by HIP events: the per-class
+        # sums and the overlapped per-launch figures of the line (scaled to the K timed steps, which ran without the brackets)
+        sym.set_profiling(1)
+        step(steps - 1)
+        cls = sym.timing()
+        sym.set_profiling(0)
+        logdets.pop()
+        bracketed_factor_ms = cls["factor_ms"]
+        for k in ("dense_ms", "n_dense_launches", "update_union_ms", "update_ms", "potrf_ms", "trsm_ms", "reduce_cells_ms", "n_update_launches"):
+            prof[k] = cls[k] * steps
 
     # ONE more, untimed evaluation with every look-ahead launch on a single side stream: consecutive launches of the
     # dominant kernel then do not overlap each other, which gives the clean per-launch duration `roofline.achieved` asks
@@ -600,7 +619,7 @@ def main():
         sym.set_profiling(2)
         step(steps - 1)  # (same sigma2 as the last timed step: the residual check below is of this solve)
         clean = sym.timing()
-        sym.set_profiling(prof_mode)
+        sym.set_profiling(timed_mode)
         logdets.pop()
     # residual check of the last solve (outside the timed region)
     fac = state["fac"]
@@ -656,7 +675,7 @@ def main():
             flops_k, n_k, ms_k = info.update_flops * K, n_upd, prof["update_ms"]
         ach_overlapped = flops_k / max(ms_k / 1e3, 1e-12) / 1e12
         ach = ach_overlapped
-        clean_note = ("launch durations of the timed steps (two launches overlap at any time)" if not args.serialised else
+        clean_note = ("launch durations of one untimed evaluation under the default schedule (two launches overlap at any time)" if not args.serialised else
                       "the timed steps themselves, run with the look-ahead launches serialised on one stream (--serialised): launch "
                       "durations do not overlap each other; rocprofv3 --kernel-trace --stats of this command shows the same average")
         if clean is not None:
@@ -723,6 +742,10 @@ def main():
                        "update_ms": prof["update_ms"] / K, "potrf_ms": prof["potrf_ms"] / K,
                        "trsm_ms": prof["trsm_ms"] / K, "main_stream_reduce_cells_ms": prof["reduce_cells_ms"] / K,
                        "launches_per_factorize": prof["n_launches"] / K,
+                       "timed_steps_instrumentation": ("none: the timed steps run without the engine's HIP-event brackets; per-class figures from "
+                                                       "one untimed bracketed evaluation (factorization %.3f ms with the brackets on)" % bracketed_factor_ms)
+                                                      if bracketed_factor_ms is not None else
+                                                      ("mode 2 brackets in every step (--serialised)" if args.serialised else "none"),
                        "symbolic_s": t_sym, "generate_s": t_gen, "first_evaluation_s": t_first,
                        "logdet": logdet_total, "solve_residual": resid},
             "roofline": {"bound": "mfma", "kernel": kern,
@@ -740,7 +763,7 @@ def main():
                          "launches": int(n_k),
                          "measured_on": clean_note,
                          "achieved_with_overlapping_launches": ach_overlapped,
-                         "note": "in the timed steps launches of consecutive levels overlap pairwise on two streams, so a launch's "
+                         "note": "under the default schedule launches of consecutive levels overlap pairwise on two streams, so a launch's "
                                  "duration is about twice what it needs alone (achieved_with_overlapping_launches); "
                                  "achieved_over_busy_time counts that overlapped time once; `achieved` is the per-launch figure "
                                  "without overlap",

@@ -46,6 +46,7 @@ struct Dev {
   int64_t nwaves_quad = 0;
   double* d_out = nullptr;         // RPMAX doubles
   bool use_mfma = true;
+  bool trsm_lite = true;           // k_trsm_lite instead of k_trsm<true> (SCILMM_TUNING=1 SCILMM_TRSM_LITE=0: the round-1 kernel)
   hipEvent_t ev[8];
   scilmm_timing timing{};
   bool quad_pending = false;           // a scilmm_quadforms_dev call whose timer has not been read yet
@@ -577,6 +578,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
     }
   const char* nm = tune_env("SCILMM_NO_MFMA");
   D->use_mfma = !(nm && nm[0] == '1');
+  const char* etl = tune_env("SCILMM_TRSM_LITE");
+  D->trsm_lite = !(etl && etl[0] == '0');
 #ifdef SCILMM_DIAG
   const char* ab = getenv("SCILMM_ABLATE");  // timing ablations (WRONG numbers): diagnostic builds only
   D->ablate = ab ? atoi(ab) : 0;
@@ -2079,7 +2082,11 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
     }
     if (prof) HIPCHK(hipEventRecord(D->pev[PE * l + 3], st));
     if (t1 > t0) {
-      if (D->use_mfma)
+      if (D->use_mfma && D->trsm_lite && (t1 - t0) < ((int64_t)1 << 29))
+        // (four workgroups of 32 rows per tile, register-light and LDS-free: starts beside the resident update kernel)
+        hipLaunchKernelGGL(k_trsm_lite, dim3((unsigned)(4 * (t1 - t0))), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD,
+                           (const int32_t*)D->d_tile_pslot, (const int32_t*)D->d_tile_pnseg, (const double*)sh);
+      else if (D->use_mfma)
         hipLaunchKernelGGL(k_trsm<true>, dim3((unsigned)(t1 - t0)), dim3(256), 0, st, D->v, D->d_level_tiles + t0, fac->L, fac->invD,
                            (const int32_t*)D->d_tile_pslot, (const int32_t*)D->d_tile_pnseg, (const double*)sh);
       else

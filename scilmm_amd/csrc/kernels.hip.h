@@ -1608,6 +1608,117 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int32_t* __restric
 
 
 // ------------------------------------------------------------------------------------------------
+// k_trsm_lite (round 4): the same panel solve, shaped to START AT ONCE beside the resident update kernel.  k_trsm<true> needs 98
+// VGPRs + 256 AGPRs and 36 KB of LDS per workgroup: beside k_dense_b (210 VGPRs x 2 waves per SIMD, 135 KB of LDS per CU) none of
+// its waves fits, so every level's trsm waited for dense items to retire -- 15 ms of the 52 ms factorization of the 100k config
+// (profiles/r4_level_timeline_100k.csv: 0.11 ms per level for 15 us of arithmetic), the largest piece of the per-level chain.
+// Here a workgroup owns 32 rows x all columns of a tile, a wave 32 rows x 32 columns (16 accumulator doubles per lane); K is
+// streamed through LDS in 16-deep chunks like k_trsm (21 KB: fits beside k_dense_b's 135 KB), the next chunk's loads in flight
+// during the MFMAs, <= 80 VGPRs (amdgpu_waves_per_eu(6)): one wave per SIMD fits into the registers k_dense_b leaves free.
+// (A first form without LDS -- fragments straight from global memory, one 4-deep k-step at a time -- did start beside the
+// update kernel but took 0.18 ms by itself: 32 dependent round trips at the loaded memory latency of a busy chip.)
+// Triangular skipping: column block jb only needs k < 16 (jb + 1).  The late partial slabs are folded on load as in k_trsm.
+constexpr int TL_ROWS = 32;
+constexpr int TL_LDA = TL_ROWS + 16;  // [k][row] image of the 32 panel rows ((ld * 8 B) == 128 mod 256: conflict-free b64 fragment reads)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void k_trsm_lite(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L, const double* __restrict__ invD,
+                 const int32_t* __restrict__ tile_pslot, const int32_t* __restrict__ tile_pnseg, const double* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) double As[KCS * TL_LDA];
+  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int32_t g = tiles[blockIdx.x >> 2];
+  const int sub = blockIdx.x & 3;                       // 32-row slab of the 128-row tile
+  const int32_t s = S.tile_front[g];
+  const int32_t ti = (int32_t)(g - S.tile_base[s]);
+  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
+  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+  const int32_t R0 = ti * TM + TL_ROWS * sub;
+  const int32_t nrow = min(TL_ROWS, m - R0);
+  if (nrow <= 0 || R0 + nrow <= w) return;              // (uniform over the workgroup) nothing below the diagonal block here
+  double* P = L + S.sn_loff[s];
+  const double* I = invD + S.inv_off[s];
+  const int32_t pn = tile_pnseg[g];
+  const int j0 = 32 * wv;                                // this wave's 32 output columns
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  // staging roles: A: thread -> row t = tid & 31, k = (tid >> 5) + 8 i (i < 2); B: column q = tid & 127, k = (tid >> 7) + 2 i (i < 8)
+  constexpr int PA = KCS / 8, PB = KCS / 2;
+  const int t = tid & 31, ka = tid >> 5;
+  const int q = tid & 127, kb = tid >> 7;
+  const bool ha = t < nrow, hb = q < w;
+  const double* pa = P + R0 + (ha ? t : 0);
+  const double* pb = I + (hb ? q : 0);
+  const double* sl = slabs + (int64_t)tile_pslot[g] * (TM * NB) + TL_ROWS * sub + (ha ? t : 0);
+  double ra[PA], rb[PB];
+  auto fetch = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ra[i] = pa[(int64_t)(k0 + min(ka + 8 * i, kc - 1)) * m];
+    for (int sg = 0; sg < pn; ++sg) {
+      const double* qs = sl + (int64_t)sg * (TM * NB);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] -= qs[(k0 + min(ka + 8 * i, kc - 1)) * TM];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = pb[(int64_t)(k0 + min(kb + 2 * i, kc - 1)) * w];
+  };
+  auto stage = [&](int k0) {
+    const int kc = min(KCS, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = ka + 8 * i;
+      if (k < kc4) As[k * TL_LDA + t] = (ha && k < kc) ? ra[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = kb + 2 * i;
+      if (k < kc4) Bs[k * LDB + q] = (hb && k < kc) ? rb[i] : 0.0;   // Aop[j][k] = invL[j][k] -> Bs[k][j]
+    }
+  };
+  fetch(0);
+  for (int32_t k0 = 0; k0 < w; k0 += KCS) {
+    const int kc = min(KCS, w - k0);
+    const int kc4 = (kc + 3) & ~3;
+    if (k0 > 0) __syncthreads();  // the previous chunk has been consumed
+    stage(k0);
+    if (k0 + KCS < w) fetch(k0 + KCS);
+    __syncthreads();
+    if (j0 < w && k0 < j0 + 32) {  // invL[j][k] = 0 for k > j: this wave's columns end at j0 + 31
+      const double* ap = Bs + lk * LDB + j0 + li;
+      const double* bp = As + lk * TL_LDA + li;
+      for (int k4 = 0; k4 < kc4; k4 += 4) {
+        const double a0 = ap[k4 * LDB], a1 = ap[k4 * LDB + 16];
+        const double b0 = bp[k4 * TL_LDA], b1 = bp[k4 * TL_LDA + 16];
+        acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+        acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+      }
+    }
+  }
+  // (every global read of the 32 rows happened before the loop's last barrier: the columns may be overwritten in place)
+  if (j0 < w) {
+#pragma unroll
+    for (int jbb = 0; jbb < 2; ++jbb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + 16 * jbb + lk + 4 * r;
+          const int i = 16 * ib + li;
+          if (i < nrow && R0 + i >= w && j < w) P[(int64_t)j * m + R0 + i] = acc[jbb][ib][r];
+        }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Right-hand-side kernels.  rp = padded column count (multiple of 16, <= RPMAX); ldy = LDS leading
 // dimension of [k][c] images (== 16 mod 32 so that b64 reads of Bop[k][c] are conflict-free).
 
