@@ -1,1006 +1,16 @@
-// RETIRED kernel variants -- tuning-harness material only (csrc/tools/dense_bench.hip); nothing in libscilmm_hip.so
-// includes this file.  Each of them was measured against the kernel that replaced it on the hot path (DESIGN.md
-// section 4: same speed or slower) and produces the same results:
-//   k_update        -> k_update2   (staging interleaved with the MFMA k-steps)
-//   k_update3       -> k_update2   (the v_mfma_f64_4x4x4 form: 67.5 vs 66.2 ms at 100k)
-//   k_dense<MF>     -> k_dense_a   (register-staged dense-tail update, both f64 MFMA forms)
-//   k_dense_g       -> k_dense_a   (both operands by LDS-DMA)
+// RETIRED kernel variants -- tuning-harness material only (csrc/tools/dense_bench2.hip); nothing in libscilmm_hip.so includes
+// this file.  What is kept is what dense_bench2 still times side by side with the kernels of the hot path (DESIGN.md sections
+// 4.0 / 4.1: every one of them same speed or slower, same results):
 //   k_dense_a       -> k_dense_b   (A from registers, B by LDS-DMA, without the in-wave software pipeline of round 3)
-//   k_update_compact               (compact-coordinate update: 66 -> 91..96 ms at 100k)
-//   k_trsm4         -> k_trsm      (the 4x4x4 form)
+//   k_dense_f / _s / _t (+ k_shadow_t) / _w   the forms that located what bounds the fp32-product fronts (-> k_dense_h)
+//   k_dense_q                      k_dense_h's 32 x 64 wave tiling for the fp64 kernel (63.6 vs k_dense_b's 68.0)
+// Pruned in round 4 (their numbers stay in DESIGN.md section 4.2, their code in the history before commit "prune the harness"):
+// k_update, k_update3, k_dense<>, k_dense_g, k_update_compact, k_trsm4 and the round-2 harness dense_bench.hip.
 // Include AFTER ../kernels.hip.h.
 #pragma once
 #include "../kernels.hip.h"
 
 namespace scilmm {
-
-// ABL (diagnostic builds only, selected by SCILMM_ABLATE): 0 = real kernel, 1 = no MFMAs, 2 = no global loads.
-template <bool MFMA, int ABL = 0>
-__global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update(DevSym S, const UpdWork* __restrict__ work,
-                                                const ComboDesc* __restrict__ combos, double* __restrict__ L,
-                                                double* __restrict__ scratch) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Abuf = smem;                         // [2][KC*LDA]
-  double* Bbuf = smem + 2 * KC * LDA;          // [2][KC*LDB]
-  int32_t* rowlab = (int32_t*)(smem + 2 * KC * LDA + 2 * KC * LDB);  // [TM]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const UpdWork wk = work[blockIdx.x];
-  const int32_t g = wk.tile;
-  const int64_t cb = wk.cb, ce = wk.ce;
-  if (cb >= ce) return;
-  const int32_t s = S.tile_front[g];
-  const int32_t ti = (int32_t)(g - S.tile_base[s]);
-  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
-  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
-  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
-  const int32_t R0 = ti * TM;
-  const int32_t nrow = min(TM, m - R0);
-  const int ncb = (w + 15) >> 4;
-  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
-  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
-  // eight waves: wave wv owns target rows [16 wv, 16 wv + 16) and all NB columns (NJB accumulator tiles)
-  d4 acc[NJB];
-#pragma unroll
-  for (int a = 0; a < NJB; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
-  // this thread's fixed roles in the staging: A row t with k phase kpa (of KA); B column q with k phase kpb (of KB)
-  constexpr int KA = UPD_THREADS / TM, KB = UPD_THREADS / NB;
-  const int t = tid % TM, kpa = tid / TM;
-  const int q = tid % NB, kpb = tid / NB;
-  // per-buffer record of what this thread wrote (so that it can clear exactly that)
-  int w_ip[2] = {-1, -1}, w_jp[2] = {-1, -1}, w_kc[2] = {0, 0};
-  // "next chunk" cursor
-  int64_t cn = cb;
-  int k0n = 0;
-  ComboDesc dn = combos[cn];
-  ComboDesc dnext = combos[min(cn + 1, ce - 1)];  // descriptor of the following combo, fetched one combo ahead
-  int ipn = -1, jpn = -1;
-  auto locate = [&]() {
-    // tile position of this thread's descendant row / target column for combo dn
-    ipn = -1;
-    jpn = -1;
-    if (t < dn.nt) {
-      if (dn.ip0 >= 0) {
-        ipn = dn.ip0 + t;
-      } else {
-        const int32_t lab = S.sn_rows[dn.rowoff + dn.ta + t];
-        int lo = 0, hi = nrow;
-        while (lo < hi) {
-          int mid = (lo + hi) >> 1;
-          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
-        }
-        ipn = lo;
-      }
-    }
-    if (q < dn.nq) jpn = (dn.jp0 >= 0) ? dn.jp0 + q : S.sn_rows[dn.rowoff + dn.p0 + q] - c0;
-  };
-  double ra[KC / KA], rb[KC / KB];
-  int kcn = 0;
-  auto prefetch = [&]() {
-    kcn = min(KC, dn.wd - k0n);
-    const double* Pd = L + dn.loff + (int64_t)k0n * dn.md;
-    const int64_t md = dn.md;
-    if (ABL == 2) {
-#pragma unroll
-      for (int i = 0; i < KC / KA; ++i) ra[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < KC / KB; ++i) rb[i] = 0.0;
-      return;
-    }
-    if (ipn >= 0) {
-      const double* pa = Pd + (int64_t)kpa * md + dn.ta + t;
-      if (kcn == KC) {
-#pragma unroll
-        for (int i = 0; i < KC / KA; ++i) ra[i] = pa[(int64_t)(KA * i) * md];
-      } else {
-#pragma unroll
-        for (int i = 0; i < KC / KA; ++i) ra[i] = (kpa + KA * i < kcn) ? pa[(int64_t)(KA * i) * md] : 0.0;
-      }
-    }
-    if (jpn >= 0) {
-      const double* pb = Pd + (int64_t)kpb * md + dn.p0 + q;
-      if (kcn == KC) {
-#pragma unroll
-        for (int i = 0; i < KC / KB; ++i) rb[i] = pb[(int64_t)(KB * i) * md];
-      } else {
-#pragma unroll
-        for (int i = 0; i < KC / KB; ++i) rb[i] = (kpb + KB * i < kcn) ? pb[(int64_t)(KB * i) * md] : 0.0;
-      }
-    }
-  };
-  // uniform (per-workgroup) record of the mapping last staged into each buffer
-  int u_ip0[2] = {-2, -2}, u_nt[2] = {0, 0}, u_jp0[2] = {-2, -2}, u_nq[2] = {0, 0}, u_kc[2] = {0, 0};
-  int s_ilo[2] = {0, 0}, s_ihi[2] = {TM - 1, TM - 1}, s_jb0[2] = {0, 0}, s_jb1[2] = {NJB - 1, NJB - 1};
-  auto stage = [&](int b) {
-    double* As = Abuf + b * KC * LDA;
-    double* Bs = Bbuf + b * KC * LDB;
-    // The cells a thread writes belong to the descendant row/column it carries, so when the mapping of
-    // the incoming chunk differs from what the buffer holds, every thread first clears its own old cells
-    // and a barrier separates the clears from the new writes (another thread may now own that cell).
-    // Consecutive chunks of the dense chains share one mapping: no clear, no extra barrier.
-    const bool same = dn.ip0 >= 0 && dn.ip0 == u_ip0[b] && dn.nt == u_nt[b] && dn.jp0 >= 0 && dn.jp0 == u_jp0[b] &&
-                      dn.nq == u_nq[b] && kcn >= u_kc[b];
-    if (!same) {
-      if (w_ip[b] >= 0) {
-#pragma unroll
-        for (int i = 0; i < KC / KA; ++i) {
-          const int k = kpa + KA * i;
-          if (k < w_kc[b]) As[k * LDA + w_ip[b]] = 0.0;
-        }
-      }
-      if (w_jp[b] >= 0) {
-#pragma unroll
-        for (int i = 0; i < KC / KB; ++i) {
-          const int k = kpb + KB * i;
-          if (k < w_kc[b]) Bs[k * LDB + w_jp[b]] = 0.0;
-        }
-      }
-      __syncthreads();
-    }
-    if (ipn >= 0) {
-      double* wa = As + kpa * LDA + ipn;
-      if (kcn == KC) {
-#pragma unroll
-        for (int i = 0; i < KC / KA; ++i) wa[KA * i * LDA] = ra[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < KC / KA; ++i)
-          if (kpa + KA * i < kcn) wa[KA * i * LDA] = ra[i];
-      }
-    }
-    if (jpn >= 0) {
-      double* wb = Bs + kpb * LDB + jpn;
-      if (kcn == KC) {
-#pragma unroll
-        for (int i = 0; i < KC / KB; ++i) wb[KB * i * LDB] = rb[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < KC / KB; ++i)
-          if (kpb + KB * i < kcn) wb[KB * i * LDB] = rb[i];
-      }
-    }
-    w_ip[b] = ipn;
-    w_jp[b] = jpn;
-    w_kc[b] = kcn;
-    u_ip0[b] = dn.ip0;
-    u_nt[b] = dn.nt;
-    u_jp0[b] = dn.jp0;
-    u_nq[b] = dn.nq;
-    u_kc[b] = kcn;
-    s_ilo[b] = dn.ilo;
-    s_ihi[b] = dn.ihi;
-    s_jb0[b] = dn.jlo >> 4;
-    s_jb1[b] = min(dn.jhi >> 4, ncb - 1);
-  };
-  auto advance = [&]() -> bool {
-    // move the cursor to the chunk after (cn, k0n); returns false at the end
-    k0n += KC;
-    if (k0n >= dn.wd) {
-      ++cn;
-      k0n = 0;
-      if (cn >= ce) return false;
-      dn = dnext;
-      dnext = combos[min(cn + 1, ce - 1)];
-      locate();
-    }
-    return true;
-  };
-  __syncthreads();  // rowlab + zeroed buffers visible
-  locate();
-  prefetch();
-  stage(0);
-  int kc4_cur = (kcn + 3) & ~3;
-  bool more = advance();
-  __syncthreads();
-  int buf = 0;
-  while (true) {
-    if (more) prefetch();  // global loads of the next chunk in flight during the MFMAs
-    if (ABL != 1 && 16 * wv <= s_ihi[buf] && 16 * wv + 15 >= s_ilo[buf])
-      tile_mma8<MFMA>(Abuf + buf * KC * LDA, Bbuf + buf * KC * LDB, kc4_cur, s_jb0[buf], s_jb1[buf], lane, wv, acc);
-    if (!more) break;
-    stage(buf ^ 1);
-    kc4_cur = (kcn + 3) & ~3;
-    more = advance();
-    __syncthreads();
-    buf ^= 1;
-  }
-  // epilogue: D[M=j][N=i] -> panel(R0+i, j) (or the partial slot); 16 consecutive lanes = 128 contiguous bytes
-  const int li = lane & 15, lr = lane >> 4;
-  if (wk.slot < 0) {
-    double* P = L + S.sn_loff[s];
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * jb + lr + 4 * r;
-        const int i = 16 * wv + li;
-        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc[jb][r];
-      }
-  } else {
-    double* Q = scratch + (int64_t)wk.slot * (TM * NB);
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * jb + lr + 4 * r;
-        const int i = 16 * wv + li;
-        Q[j * TM + i] = acc[jb][r];
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_update3: k_update2 with the matrix pipe driven by v_mfma_f64_4x4x4f64 (four independent 4x4x4 blocks per
-// instruction) instead of v_mfma_f64_16x16x4_f64.  Measured on this GPU (csrc/tools/mfma_sweep.hip,
-// profiles/r2_mfma_sweep.txt): the 16x16x4 form issues every ~105 cycles per SIMD (49 TFLOP/s chip-wide, whatever the
-// number of busy CUs), the 4x4x4 form every ~17 cycles for a quarter of the flops = 75 TFLOP/s, 95 % of the
-// 78.6 TFLOP/s datasheet figure.  The price is operand bandwidth (64 + 64 operand values per 256 MACs instead of
-// per 1024), paid from registers: per k-step a wave reads its 4 row operands (rows replicated over the 4 blocks:
-// an LDS broadcast) and 8 column operands once and issues 8 x 4 MFMAs on them -- 12 LDS reads per 32 MFMAs.
-// Lane roles of the instruction as probed on gfx950 (csrc/tools/mfma_probe.hip, profiles/r2_mfma_probe.txt):
-//   A operand: lane = 16 k + 4 block + i      B operand: lane = 16 k + 4 block + j      D: lane = 16 i + 4 block + j
-// Used here with the COLUMN operand as A, replicated over the blocks (4 target columns x 4 k), and the ROW operand
-// as B (rows 4 block + j: 16 tile rows x 4 k), so one instruction updates a 16-row x 4-column piece of the tile and
-// result lane l holds row (l & 15), column (l >> 4) of it: 16 consecutive lanes = 16 consecutive rows of one panel
-// column (128 contiguous bytes in the epilogue, like the 16x16x4 form).  Wave wv owns target columns
-// [16 wv, 16 wv + 16) x all 128 rows as 8 x 4 such pieces.
-template <bool MFMA>
-__global__ __launch_bounds__(UPD_THREADS, SCILMM_UPD_WAVES) void k_update3(DevSym S, const UpdWork* __restrict__ work,
-                                                 const ComboDesc* __restrict__ combos, double* __restrict__ L,
-                                                 double* __restrict__ scratch) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Abuf = smem;                         // [2][KC*LDA]
-  double* Bbuf = smem + 2 * KC * LDA;          // [2][KC*LDB]
-  int32_t* rowlab = (int32_t*)(smem + 2 * KC * LDA + 2 * KC * LDB);  // [TM]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const UpdWork wk = work[blockIdx.x];
-  const int32_t g = wk.tile;
-  const int64_t cb = wk.cb, ce = wk.ce;
-  if (cb >= ce) return;
-  const int32_t s = S.tile_front[g];
-  const int32_t ti = (int32_t)(g - S.tile_base[s]);
-  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
-  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
-  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
-  const int32_t R0 = ti * TM;
-  const int32_t nrow = min(TM, m - R0);
-  const int ncb = (w + 15) >> 4;
-  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
-  for (int idx = tid; idx < 2 * KC * LDA + 2 * KC * LDB; idx += UPD_THREADS) smem[idx] = 0.0;
-  // acc4[p][q]: this lane's element of the piece (rows 16 p .., columns 16 wv + 4 q ..): one double per MFMA
-  constexpr int NRB = TM / 16;
-  double acc4[NRB][4];
-#pragma unroll
-  for (int a = 0; a < NRB; ++a)
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) acc4[a][q4] = 0.0;
-  const int l15 = lane & 15, l3 = lane & 3, lk4 = lane >> 4;
-  constexpr int KA = UPD_THREADS / TM, KB = UPD_THREADS / NB;
-  constexpr int NPA = KC / KA, NPB = KC / KB, NS = KC / 4;  // pieces of A / B per thread, k-steps per chunk
-  static_assert(NPA <= NS && NPB <= NS, "staging pieces must fit the k-steps of a chunk");
-  const int t = tid % TM, kpa = tid / TM;
-  const int q = tid % NB, kpb = tid / NB;
-  // ---- three pipeline stages: L = being loaded into registers, W = being written to LDS, C = being multiplied
-  struct Stage {
-    int ip, jp, kc;              // this thread's tile row / target column (-1: none) and the chunk depth
-    int la, lb;                  // LDS cell offsets: the row / column, or this thread's private pad cell
-    int ip0, nt, jp0, nq;        // uniform mapping (for the same-cells test)
-    int ilo, ihi, jb0, jb1;      // spans (for MFMA skipping)
-    bool valid;
-  };
-  Stage SL{}, SW{}, SC{};
-  int64_t cn = cb;  // cursor of the load stage
-  int k0n = 0;
-  ComboDesc dn = combos[cn];
-  ComboDesc dnext = combos[min(cn + 1, ce - 1)];
-  const double* gpa = nullptr;  // this thread's global read pointers for the load-stage chunk
-  const double* gpb = nullptr;
-  int64_t gmd = 0;
-  auto locate_L = [&]() {
-    SL.valid = true;
-    SL.ip = -1;
-    SL.jp = -1;
-    if (t < dn.nt) {
-      if (dn.ip0 >= 0) {
-        SL.ip = dn.ip0 + t;
-      } else {
-        const int32_t lab = S.sn_rows[dn.rowoff + dn.ta + t];
-        int lo = 0, hi = nrow;
-        while (lo < hi) {
-          int mid = (lo + hi) >> 1;
-          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
-        }
-        SL.ip = lo;
-      }
-    }
-    if (q < dn.nq) SL.jp = (dn.jp0 >= 0) ? dn.jp0 + q : S.sn_rows[dn.rowoff + dn.p0 + q] - c0;
-    SL.la = SL.ip >= 0 ? SL.ip : TM + (t & 15);
-    SL.lb = SL.jp >= 0 ? SL.jp : NB + (q & 15);
-    SL.ip0 = dn.ip0; SL.nt = dn.nt; SL.jp0 = dn.jp0; SL.nq = dn.nq;
-    SL.ilo = dn.ilo; SL.ihi = dn.ihi; SL.jb0 = dn.jlo >> 4; SL.jb1 = min(dn.jhi >> 4, ncb - 1);
-  };
-  auto point_L = [&]() {
-    SL.kc = min(KC, dn.wd - k0n);
-    gmd = dn.md;
-    const double* Pd = L + dn.loff + (int64_t)k0n * gmd;
-    // threads without a row / column of this combo read a valid neighbour's element (the value is never used:
-    // it lands in that thread's private LDS pad cell), so the hot loop needs no per-thread predicate
-    gpa = Pd + dn.ta + (SL.ip >= 0 ? t : 0);
-    gpb = Pd + dn.p0 + (SL.jp >= 0 ? q : 0);
-  };
-  auto advance_L = [&]() {
-    // move the load cursor to the next chunk; invalidates SL at the end of the work item
-    k0n += KC;
-    if (k0n >= dn.wd) {
-      ++cn;
-      k0n = 0;
-      if (cn >= ce) { SL.valid = false; return; }
-      dn = dnext;
-      dnext = combos[min(cn + 1, ce - 1)];
-      locate_L();
-    }
-    point_L();
-  };
-  double ra[NPA], rb[NPB];
-  // branch-free pieces: k is clamped into the chunk for the load, and rows beyond the chunk depth are written as
-  // zeros (so every cell a thread owns in a buffer is rewritten by every chunk: no stale k rows)
-  auto load_piece = [&](int i) {
-    if (i < NPA) ra[i] = gpa[(int64_t)min(kpa + KA * i, SL.kc - 1) * gmd];
-    if (i < NPB) rb[i] = gpb[(int64_t)min(kpb + KB * i, SL.kc - 1) * gmd];
-  };
-  auto write_piece = [&](int i, double* As, double* Bs) {
-    if (i < NPA) As[(kpa + KA * i) * LDA + SW.la] = (kpa + KA * i < SW.kc) ? ra[i] : 0.0;
-    if (i < NPB) Bs[(kpb + KB * i) * LDB + SW.lb] = (kpb + KB * i < SW.kc) ? rb[i] : 0.0;
-  };
-  // what each LDS buffer currently holds (per-thread cells + uniform mapping)
-  int h_ip[2] = {-1, -1}, h_jp[2] = {-1, -1}, h_kc[2] = {0, 0};
-  int u_ip0[2] = {-2, -2}, u_nt[2] = {0, 0}, u_jp0[2] = {-2, -2}, u_nq[2] = {0, 0};
-  auto same_cells = [&](int b) -> bool {
-    return SW.ip0 >= 0 && SW.ip0 == u_ip0[b] && SW.nt == u_nt[b] && SW.jp0 >= 0 && SW.jp0 == u_jp0[b] && SW.nq == u_nq[b];
-  };
-  auto clear_own = [&](int b) {
-    double* As = Abuf + b * KC * LDA;
-    double* Bs = Bbuf + b * KC * LDB;
-    if (h_ip[b] >= 0) {
-#pragma unroll
-      for (int i = 0; i < NPA; ++i) As[(kpa + KA * i) * LDA + h_ip[b]] = 0.0;
-    }
-    if (h_jp[b] >= 0) {
-#pragma unroll
-      for (int i = 0; i < NPB; ++i) Bs[(kpb + KB * i) * LDB + h_jp[b]] = 0.0;
-    }
-  };
-  auto record = [&](int b) {
-    h_ip[b] = SW.ip; h_jp[b] = SW.jp; h_kc[b] = SW.kc;
-    u_ip0[b] = SW.ip0; u_nt[b] = SW.nt; u_jp0[b] = SW.jp0; u_nq[b] = SW.nq;
-  };
-  __syncthreads();  // rowlab + zeroed buffers visible
-  // ---- prologue: chunk 0 -> registers -> buffer 0; chunk 1 -> registers
-  locate_L();
-  point_L();
-#pragma unroll
-  for (int i = 0; i < NS; ++i) load_piece(i);
-  SW = SL;
-  advance_L();
-#pragma unroll
-  for (int i = 0; i < NS; ++i) write_piece(i, Abuf, Bbuf);
-  record(0);
-  if (SL.valid) {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) load_piece(i);
-  }
-  SC = SW;
-  SW = SL;
-  if (SL.valid) advance_L();
-  __syncthreads();
-  int buf = 0;
-  while (true) {
-    double* Aw = Abuf + (buf ^ 1) * KC * LDA;
-    double* Bw = Bbuf + (buf ^ 1) * KC * LDB;
-    if (SW.valid && !same_cells(buf ^ 1)) {
-      clear_own(buf ^ 1);
-      __syncthreads();
-    }
-    const double* Ac = Abuf + buf * KC * LDA;
-    const double* Bc = Bbuf + buf * KC * LDB;
-    const int kc4 = (SC.kc + 3) & ~3;
-    const bool mine = wv >= SC.jb0 && wv <= SC.jb1;     // this wave's 16 columns lie inside the chunk's column span
-    const int plo = SC.ilo >> 4, phi = SC.ihi >> 4;     // 16-row groups inside its row span
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      if (SW.valid) write_piece(i, Aw, Bw);
-      if (SL.valid) load_piece(i);
-      if (mine && 4 * i < kc4) {
-        if (MFMA) {
-          double cv[4];
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) cv[q4] = Bc[(4 * i + lk4) * LDB + 16 * wv + 4 * q4 + l3];
-#pragma unroll
-          for (int pr = 0; pr < NRB; ++pr)
-            if (pr >= plo && pr <= phi) {
-              const double rv = Ac[(4 * i + lk4) * LDA + 16 * pr + l15];
-#pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[q4], rv, acc4[pr][q4], 0, 0, 0);
-            }
-        } else {
-          for (int k = 4 * i; k < 4 * i + 4; ++k)
-#pragma unroll
-            for (int pr = 0; pr < NRB; ++pr)
-              if (pr >= plo && pr <= phi)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] += Bc[k * LDB + 16 * wv + 4 * q4 + lk4] * Ac[k * LDA + 16 * pr + l15];
-        }
-      }
-    }
-    if (!SW.valid) break;
-    record(buf ^ 1);
-    SC = SW;
-    SW = SL;
-    if (SL.valid) advance_L();
-    __syncthreads();
-    buf ^= 1;
-  }
-  // epilogue: piece (p, q), lane l -> tile row 16 p + (l & 15), target column 16 wv + 4 q + (l >> 4)
-  if (wk.slot < 0) {
-    double* P = L + S.sn_loff[s];
-#pragma unroll
-    for (int pr = 0; pr < NRB; ++pr)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int j = 16 * wv + 4 * q4 + lk4;
-        const int i = 16 * pr + l15;
-        if (i < nrow && j < w) P[(int64_t)j * m + R0 + i] -= acc4[pr][q4];
-      }
-  } else {
-    double* Q = scratch + (int64_t)wk.slot * (TM * NB);
-#pragma unroll
-    for (int pr = 0; pr < NRB; ++pr)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int j = 16 * wv + 4 * q4 + lk4;
-        const int i = 16 * pr + l15;
-        Q[j * TM + i] = acc4[pr][q4];
-      }
-  }
-}
-
-template <int MF, bool MFMA>
-__global__ __launch_bounds__(512, 1) void k_dense(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
-                                                  double* __restrict__ L, double* __restrict__ scratch) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Abuf = smem;                      // [2][KC][LDA2]
-  double* Bbuf = smem + 2 * KC * LDA2;      // [2][KC][LDB]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef SCILMM_DENSE_CLK
-  const unsigned long long clk_w0 = wall_clock64(), clk_c0 = clock64();
-#endif
-  const DenseWork wk = work[blockIdx.x];
-  const int32_t j = wk.front;
-  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
-  const int32_t mj = S.n - c0j;             // dense tail: the rows of front j are the labels c0j .. n-1
-  const int32_t R0 = wk.ti0 * TM;
-  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
-#if SCILMM_DENSE_VEC
-  // staging roles, 16 bytes per access: A row PAIR pa (rows 2 pa, 2 pa + 1) with k phase ka (of 4), B column pair pb
-  // with k phase kb (of 8).  Rows / columns of a panel column are contiguous, so a pair is one 16-byte global load
-  // (8-byte aligned: the leading dimension may be odd) and one ds_write_b128: half the load and store instructions.
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  constexpr int NPA = KC / 4, NPB = KC / 8;
-  const int pa = tid & (DTR / 2 - 1), ka = tid >> 7;
-  const int pb = tid & (NB / 2 - 1), kb = tid >> 6;
-  // a pair that starts inside the range is loaded where it is (at an odd edge its second element is the first one past
-  // the range: valid memory -- the next rows of the column, the next column, or the slack behind L -- and its LDS cell
-  // is never read back into a stored result); pairs beyond the range re-read pair 0
-  const int ra_row = 2 * pa < nrow ? 2 * pa : 0, rb_col = 2 * pb < wj ? 2 * pb : 0;
-  d2 ra[NPA], rb[NPB];
-  int32_t kd = wk.k0;   // descendant cursor of the chunk being loaded
-  int32_t kk0 = 0;      // first column of that chunk inside the descendant
-  int kc_ld = 0;        // depth of the chunk held in ra / rb
-  auto load_chunk = [&]() {
-    const int32_t d = dense_first + kd;
-    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
-    const int64_t md = S.n - c0d;
-    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
-    kc_ld = min(KC, wd - kk0);
-    if (SCILMM_DENSE_ABL != 2 || (kd == wk.k0 && kk0 == 0)) {
-#pragma unroll
-      for (int i = 0; i < NPA; ++i) {
-        const double* q = Pd + (int64_t)min(ka + 4 * i, kc_ld - 1) * md + R0 + ra_row;
-        __builtin_memcpy(&ra[i], q, 16);
-      }
-#pragma unroll
-      for (int i = 0; i < NPB; ++i) {
-        const double* q = Pd + (int64_t)min(kb + 8 * i, kc_ld - 1) * md + rb_col;
-        __builtin_memcpy(&rb[i], q, 16);
-      }
-    }
-    kk0 += KC;
-    if (kk0 >= wd) { kk0 = 0; ++kd; }
-  };
-  auto store_chunk = [&](int b) {
-    double* As = Abuf + b * KC * LDA2;
-    double* Bs = Bbuf + b * KC * LDB;
-    const d2 zero = (d2){0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) *(d2*)&As[(ka + 4 * i) * LDA2 + 2 * pa] = (ka + 4 * i < kc_ld) ? ra[i] : zero;
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) *(d2*)&Bs[(kb + 8 * i) * LDB + 2 * pb] = (kb + 8 * i < kc_ld) ? rb[i] : zero;
-  };
-#else
-  // staging roles: A row ta with k phase ka (of 2), B column tb with k phase kb (of 4)
-  constexpr int NPA = KC / 2, NPB = KC / 4;
-  const int ta = tid & (DTR - 1), ka = tid >> 8;
-  const int tb = tid & (NB - 1), kb = tid >> 7;
-  const int ra_row = min(ta, nrow - 1), rb_col = min(tb, wj - 1);  // clamped: every load is unconditional
-  double ra[NPA], rb[NPB];
-  int32_t kd = wk.k0;   // descendant cursor of the chunk being loaded
-  int32_t kk0 = 0;      // first column of that chunk inside the descendant
-  int kc_ld = 0;        // depth of the chunk held in ra / rb
-  auto load_chunk = [&]() {
-    const int32_t d = dense_first + kd;
-    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
-    const int64_t md = S.n - c0d;
-    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
-    kc_ld = min(KC, wd - kk0);
-    if (SCILMM_DENSE_ABL != 2 || (kd == wk.k0 && kk0 == 0)) {
-#pragma unroll
-      for (int i = 0; i < NPA; ++i) ra[i] = Pd[(int64_t)min(ka + 2 * i, kc_ld - 1) * md + R0 + ra_row];
-#pragma unroll
-      for (int i = 0; i < NPB; ++i) rb[i] = Pd[(int64_t)min(kb + 4 * i, kc_ld - 1) * md + rb_col];
-    }
-    kk0 += KC;
-    if (kk0 >= wd) { kk0 = 0; ++kd; }
-  };
-  auto store_chunk = [&](int b) {
-    double* As = Abuf + b * KC * LDA2;
-    double* Bs = Bbuf + b * KC * LDB;
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) As[(ka + 2 * i) * LDA2 + ta] = (ka + 2 * i < kc_ld) ? ra[i] : 0.0;
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) Bs[(kb + 4 * i) * LDB + tb] = (kb + 4 * i < kc_ld) ? rb[i] : 0.0;
-  };
-#endif
-  // accumulators (64 doubles per lane in both forms)
-  d4 acc16[NJB][2];
-  double acc4[DTR / 16][4];
-  if (MF == 16) {
-#pragma unroll
-    for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
-  } else {
-#pragma unroll
-    for (int a = 0; a < DTR / 16; ++a)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) acc4[a][q4] = 0.0;
-  }
-  const int li = lane & 15, lk = lane >> 4, l3 = lane & 3;
-  if (wk.k0 >= wk.k1) return;
-  load_chunk();
-  int kc_cur = kc_ld;
-  store_chunk(0);
-  __syncthreads();
-  int buf = 0;
-  while (true) {
-    const bool more = kd < wk.k1;
-    if (more) load_chunk();  // global loads of the next chunk in flight during the MFMAs of this one
-    const double* Ac = Abuf + buf * KC * LDA2;
-    const double* Bc = Bbuf + buf * KC * LDB;
-    const int kc4 = (kc_cur + 3) & ~3;
-    if (MFMA && MF == 16) {
-      // wave wv: rows [32 wv, 32 wv + 32) x all 128 columns;  D[M = column][N = row]
-#pragma unroll 2
-      for (int k4 = 0; k4 < kc4; k4 += 4) {
-        const double a0 = Ac[(k4 + lk) * LDA2 + 32 * wv + li], a1 = Ac[(k4 + lk) * LDA2 + 32 * wv + 16 + li];
-        double b[NJB];
-#pragma unroll
-        for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
-#pragma unroll
-        for (int jb = 0; jb < NJB; ++jb) {
-          acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
-          acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
-        }
-      }
-    } else if (MFMA) {
-      // wave wv: columns [16 wv, 16 wv + 16) x all 256 rows as 16 x 4 pieces of 16 rows x 4 columns
-#pragma unroll 2
-      for (int k4 = 0; k4 < kc4; k4 += 4) {
-        double cv[4];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) cv[q4] = Bc[(k4 + lk) * LDB + 16 * wv + 4 * q4 + l3];
-#pragma unroll
-        for (int pr = 0; pr < DTR / 16; ++pr) {
-          const double rv = Ac[(k4 + lk) * LDA2 + 16 * pr + li];
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[q4], rv, acc4[pr][q4], 0, 0, 0);
-        }
-      }
-    } else {
-      // scalar restatement in the layout of the 4x4x4 form (debug path)
-      for (int k = 0; k < kc4; ++k)
-#pragma unroll
-        for (int pr = 0; pr < DTR / 16; ++pr)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) acc4[pr][q4] += Bc[k * LDB + 16 * wv + 4 * q4 + lk] * Ac[k * LDA2 + 16 * pr + li];
-    }
-    if (!more) break;
-    if (SCILMM_DENSE_ABL != 3) store_chunk(buf ^ 1);
-    kc_cur = kc_ld;
-    __syncthreads();
-    buf ^= 1;
-  }
-  if (SCILMM_DENSE_ABL == 1) {  // keep the accumulators alive without the stores
-    double sacc = 0.0;
-    if (MF == 16) {
-#pragma unroll
-      for (int a = 0; a < NJB; ++a) sacc += acc16[a][0][0] + acc16[a][0][1] + acc16[a][0][2] + acc16[a][0][3] + acc16[a][1][0] + acc16[a][1][1] + acc16[a][1][2] + acc16[a][1][3];
-    } else {
-#pragma unroll
-      for (int a = 0; a < DTR / 16; ++a) sacc += acc4[a][0] + acc4[a][1] + acc4[a][2] + acc4[a][3];
-    }
-    if (sacc == 123.456) scratch[0] = sacc;
-    return;
-  }
-#ifdef SCILMM_DENSE_CLK
-  if (tid == 0) {
-    atomicAdd(&g_dense_clk[0], wall_clock64() - clk_w0);
-    atomicAdd(&g_dense_clk[1], clock64() - clk_c0);
-  }
-#endif
-  // epilogue: tile h = 0 / 1 (rows [128 h, 128 h + 128) of the item) -> panel or its partial slab
-  double* P = L + S.sn_loff[j];
-  auto put = [&](int i, int jc, double v) {
-    const int h = i >> 7;
-    const int32_t slot = h ? wk.slot1 : wk.slot0;
-    if (slot < 0) {
-      if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
-    } else if (h < wk.ntiles) {
-      scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
-    }
-  };
-  if (MFMA && MF == 16) {
-#pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) put(32 * wv + 16 * ib + li, 16 * jb + lk + 4 * r, acc16[jb][ib][r]);
-  } else {
-#pragma unroll
-    for (int pr = 0; pr < DTR / 16; ++pr)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) put(16 * pr + li, 16 * wv + 4 * q4 + lk, acc4[pr][q4]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_dense_g: k_dense<16, true> with the staging done by LDS-DMA (global_load_lds_dwordx4, gfx950): a wave-instruction
-// moves 64 x 16 bytes from per-lane global addresses straight into 1 KiB of contiguous LDS -- exactly one k-row of
-// the B image (128 columns) or half a k-row of the A image (128 of the 256 rows), the padding between k-rows stays.
-// No staging registers, no ds_write pass, no selects: the copy of chunk c+1 into the other buffer is issued right
-// after the barrier that retired that buffer's readers and lands while the MFMAs of chunk c run; one vmcnt(0) +
-// barrier per chunk.  k-rows past the end of a descendant are sourced from a zero page (`zeros`, >= 1 KiB), rows /
-// columns past the item's edge from row / column 0 (their accumulators are never stored).
-// (Measured and dropped: spreading the six DMA issues of a wave behind the MFMAs of the four k-steps instead of ahead
-// of them -- with the builtin hipcc drains the DMA before the next fragment read, 19.8 instead of 56.6 TFLOP/s alone;
-// from an asm statement, which it does not count, the statement's memory clobber still stops the fragment reads of
-// the next k-step from moving above it, 28.8 TFLOP/s.  The asm form issued in one go equals the builtin.)
-
-__global__ __launch_bounds__(512, 1) void k_dense_g(DevSym S, int32_t dense_first, const DenseWork* __restrict__ work,
-                                                    double* __restrict__ L, double* __restrict__ scratch,
-                                                    const double* __restrict__ zeros) {
-  static_assert(KC == 16 && NB == 128 && DTR == 256, "k_dense_g: 8 waves x (2 A k-rows x 2 halves + 2 B k-rows) per chunk");
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* Abuf = smem;                      // [2][KC][LDA2]
-  double* Bbuf = smem + 2 * KC * LDA2;      // [2][KC][LDB]
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const DenseWork wk = work[blockIdx.x];
-  const int32_t j = wk.front;
-  const int32_t c0j = S.sn_start[j], wj = S.sn_start[j + 1] - c0j;
-  const int32_t mj = S.n - c0j;
-  const int32_t R0 = wk.ti0 * TM;
-  const int32_t nrow = min(wk.ntiles * TM, mj - R0);
-  // per-lane source offsets (doubles) inside a panel column: row pair of each A half, column pair of B
-  const int32_t a_off0 = R0 + (2 * lane < nrow ? 2 * lane : 0);
-  const int32_t a_off1 = R0 + (TM + 2 * lane < nrow ? TM + 2 * lane : 0);
-  const int32_t b_off = 2 * lane < wj ? 2 * lane : 0;
-  const double* zsrc = zeros + 2 * lane;
-  int32_t kd = wk.k0, kk0 = 0;
-  int kc_ld = 0;
-  auto issue_chunk = [&](int b) {
-    const int32_t d = dense_first + kd;
-    const int32_t c0d = S.sn_start[d], wd = S.sn_start[d + 1] - c0d;
-    const int64_t md = S.n - c0d;
-    const double* Pd = L + S.sn_loff[d] + (int64_t)kk0 * md + (c0j - c0d);
-    kc_ld = min(KC, wd - kk0);
-    double* As = Abuf + b * KC * LDA2;
-    double* Bs = Bbuf + b * KC * LDB;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kr = 2 * wv + i;
-      const double* col = Pd + (int64_t)kr * md;
-      const bool in = kr < kc_ld;
-      __builtin_amdgcn_global_load_lds((gl_vptr)(in ? col + a_off0 : zsrc), (lds_vptr)(As + kr * LDA2), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gl_vptr)(in ? col + a_off1 : zsrc), (lds_vptr)(As + kr * LDA2 + TM), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kr = wv + 8 * i;
-      const bool in = kr < kc_ld;
-      __builtin_amdgcn_global_load_lds((gl_vptr)(in ? Pd + (int64_t)kr * md + b_off : zsrc), (lds_vptr)(Bs + kr * LDB), 16, 0, 0);
-    }
-    kk0 += KC;
-    if (kk0 >= wd) { kk0 = 0; ++kd; }
-  };
-  d4 acc16[NJB][2];
-#pragma unroll
-  for (int a = 0; a < NJB; ++a) { acc16[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc16[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
-  const int li = lane & 15, lk = lane >> 4;
-  if (wk.k0 >= wk.k1) return;
-  issue_chunk(0);
-  int kc_cur = kc_ld;
-  __syncthreads();  // (hipcc drains the outstanding LDS-DMA -- vmcnt(0) -- ahead of the barrier)
-  int buf = 0;
-  while (true) {
-    const bool more = kd < wk.k1;
-    if (more) issue_chunk(buf ^ 1);
-    const double* Ac = Abuf + buf * KC * LDA2;
-    const double* Bc = Bbuf + buf * KC * LDB;
-    const int kc4 = (kc_cur + 3) & ~3;
-#pragma unroll 2
-    for (int k4 = 0; k4 < kc4; k4 += 4) {
-      const double a0 = Ac[(k4 + lk) * LDA2 + 32 * wv + li], a1 = Ac[(k4 + lk) * LDA2 + 32 * wv + 16 + li];
-      double b[NJB];
-#pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) b[jb] = Bc[(k4 + lk) * LDB + 16 * jb + li];
-#pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
-        acc16[jb][0] = mfma_f64(b[jb], a0, acc16[jb][0]);
-        acc16[jb][1] = mfma_f64(b[jb], a1, acc16[jb][1]);
-      }
-    }
-    if (!more) break;
-    kc_cur = kc_ld;
-    __syncthreads();
-    buf ^= 1;
-  }
-  double* P = L + S.sn_loff[j];
-#pragma unroll
-  for (int jb = 0; jb < NJB; ++jb)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 32 * wv + 16 * ib + li, jc = 16 * jb + lk + 4 * r;
-        const double v = acc16[jb][ib][r];
-        const int h = i >> 7;
-        const int32_t slot = h ? wk.slot1 : wk.slot0;
-        if (slot < 0) {
-          if (i < nrow && jc < wj) P[(int64_t)jc * mj + R0 + i] -= v;
-        } else if (h < wk.ntiles) {
-          scratch[(int64_t)slot * (TM * NB) + jc * TM + (i & (TM - 1))] = v;
-        }
-      }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Compact path of the supernodal update: combos whose rows / columns are scattered over the target tile
-// (a family subtree updating a few dozen of the 128 x 128 cells' rows and columns) would keep all eight
-// waves and all column blocks of k_update busy although only ceil(nt/16) x ceil(nq/16) blocks carry data.
-// Here such a combo is multiplied in ITS OWN coordinates (rows ta.. and p0.. of the descendant, staged
-// contiguously), and the nt x nq result is subtracted from the panel cell by cell.  A work item owns one half
-// (64 rows) of a tile and runs after the dense update and its reduce on the same stream, so it is the only
-// writer of its cells; fixed order of its combos + one writer per cell per combo => bitwise reproducible (the L2
-// atomics of one combo are drained before the next one starts).
-constexpr int KCQ = 16;  // K depth per staging chunk of the compact path
-
-template <bool MFMA>
-__global__ __launch_bounds__(256) void k_update_compact(DevSym S, const UpdWork* __restrict__ work,
-                                                        const ComboDesc* __restrict__ combos, double* __restrict__ L,
-                                                        double* __restrict__ slabs) {
-  // slabs == nullptr: the item owns its half tile and subtracts from the panel.  Otherwise it accumulates into
-  // its private partial slab slabs[slot] (zeroed here; k_reduce folds it) and may run beside other writers.
-  __shared__ __attribute__((aligned(16))) double As[KCQ * LDA];  // [k][t]  descendant rows of the tile (compact)
-  __shared__ __attribute__((aligned(16))) double Bs[KCQ * LDB];  // [k][q]  descendant rows = target columns (compact)
-  __shared__ int32_t rowlab[TM];
-  __shared__ int32_t pos[TM];   // compact row t -> tile position
-  __shared__ int32_t col[NB];   // compact column q -> target column
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const UpdWork wk = work[blockIdx.x];
-  const int32_t g = wk.tile;
-  const int32_t s = S.tile_front[g];
-  const int32_t ti = (int32_t)(g - S.tile_base[s]);
-  const int32_t c0 = S.sn_start[s];
-  const int32_t* rs = S.sn_rows + S.sn_rowptr[s];
-  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
-  const int32_t R0 = ti * TM;
-  const int32_t nrow = min(TM, m - R0);
-  double* Q = slabs ? slabs + (int64_t)wk.slot * (TM * NB) : L + S.sn_loff[s] + R0;  // cell (i, j) at Q[j * ldq + i]
-  const int64_t ldq = slabs ? TM : m;
-  const double sgn = slabs ? 1.0 : -1.0;
-  if (slabs)
-    for (int idx = tid; idx < TM * NB; idx += 256) Q[idx] = 0.0;
-  if (tid < TM) rowlab[tid] = tid < nrow ? rs[R0 + tid] : 0x7fffffff;
-  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab zeros are in L2 before the first atomic of this item
-  __syncthreads();
-  for (int64_t c = wk.cb; c < wk.ce; ++c) {
-    const ComboDesc d = combos[c];
-    if (tid < d.nt) {
-      int p;
-      if (d.ip0 >= 0) {
-        p = d.ip0 + tid;
-      } else {
-        const int32_t lab = S.sn_rows[d.rowoff + d.ta + tid];
-        int lo = 0, hi = nrow;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (rowlab[mid] < lab) lo = mid + 1; else hi = mid;
-        }
-        p = lo;
-      }
-      pos[tid] = p;
-    }
-    if (tid >= 128 && tid - 128 < d.nq) {
-      const int q = tid - 128;
-      col[q] = (d.jp0 >= 0) ? d.jp0 + q : S.sn_rows[d.rowoff + d.p0 + q] - c0;
-    }
-    const int bq = (d.nq + 15) >> 4;
-    const int nblk = ((d.nt + 15) >> 4) * bq;  // <= 16 by the host's classification
-    d4 acc[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) acc[a] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double* Pd = L + d.loff;
-    const int64_t md = d.md;
-    for (int k0 = 0; k0 < d.wd; k0 += KCQ) {
-      const int kc = min(KCQ, d.wd - k0);
-      const int kc4 = (kc + 3) & ~3;
-      __syncthreads();  // the previous chunk has been consumed
-      {
-        // 256 threads: thread (x = tid & 127, kk = tid >> 7) stages k = kk, kk + 2, ... of row x for A and for B
-        const int x = tid & 127, kk = tid >> 7;
-        const bool ha = x < d.nt, hb = x < d.nq;
-        const double* pa = Pd + (int64_t)(k0 + kk) * md + d.ta + (ha ? x : 0);
-        const double* pb = Pd + (int64_t)(k0 + kk) * md + d.p0 + (hb ? x : 0);
-        double va[KCQ / 2], vb[KCQ / 2];
-#pragma unroll
-        for (int i = 0; i < KCQ / 2; ++i) {
-          const int k = min(kk + 2 * i, kc - 1) - kk;  // clamped into the chunk: unconditional, independent loads
-          va[i] = pa[(int64_t)k * md];
-          vb[i] = pb[(int64_t)k * md];
-        }
-#pragma unroll
-        for (int i = 0; i < KCQ / 2; ++i) {
-          const int k = kk + 2 * i;
-          if (k < kc4) {
-            As[k * LDA + x] = (ha && k < kc) ? va[i] : 0.0;
-            Bs[k * LDB + x] = (hb && k < kc) ? vb[i] : 0.0;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int b = wv + 4 * a;
-        if (b < nblk) {
-          const int ib = b / bq, jb = b - ib * bq;
-          if (MFMA) {
-            for (int k4 = 0; k4 < kc4; k4 += 4)
-              acc[a] = mfma_f64(Bs[(k4 + lk) * LDB + 16 * jb + li], As[(k4 + lk) * LDA + 16 * ib + li], acc[a]);
-          } else {
-            for (int k = 0; k < kc4; ++k)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[a][r] += Bs[k * LDB + 16 * jb + lk + 4 * r] * As[k * LDA + 16 * ib + li];
-          }
-        }
-      }
-    }
-    // scatter: D[M = q][N = t] -> slab(col[q], pos[t]); one writer per cell within a combo
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int b = wv + 4 * a;
-      if (b < nblk) {
-        const int ib = b / bq, jb = b - ib * bq;
-        const int t = 16 * ib + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = 16 * jb + lk + 4 * r;
-          if (t < d.nt && q < d.nq) unsafeAtomicAdd(&Q[(int64_t)col[q] * ldq + pos[t]], sgn * acc[a][r]);
-        }
-      }
-    }
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this combo's adds are complete before the next combo's
-    __syncthreads();                                       // (fixed summation order), and pos / col may be rewritten
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_trsm4: k_trsm with the product on v_mfma_f64_4x4x4f64 (see k_update3 for the lane roles and why it is the faster
-// form on gfx950: this launch is one 128 x 128 x 128 product per workgroup at one wave per SIMD, i.e. pure MFMA
-// issue latency -- 2048 instructions of 17 cycles per wave instead of 512 of 140).  Wave wv owns target columns
-// [32 wv, 32 wv + 32) x all 128 rows as 8 x 8 pieces of 16 rows x 4 columns.
-__global__ __launch_bounds__(256) void k_trsm4(DevSym S, const int32_t* __restrict__ tiles, double* __restrict__ L,
-                                               const double* __restrict__ invD) {
-  __shared__ __attribute__((aligned(16))) double As[KCS * LDA];
-  __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int32_t g = tiles[blockIdx.x];
-  const int32_t s = S.tile_front[g];
-  const int32_t ti = (int32_t)(g - S.tile_base[s]);
-  const int32_t c0 = S.sn_start[s], w = S.sn_start[s + 1] - c0;
-  const int32_t m = (int32_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
-  const int32_t R0 = ti * TM;
-  const int32_t nrow = min(TM, m - R0);
-  if (R0 + nrow <= w) return;  // tile lies entirely inside the diagonal block
-  double* P = L + S.sn_loff[s];
-  const double* I = invD + S.inv_off[s];
-  constexpr int NRB = TM / 16, NQ = 8;
-  double acc4[NRB][NQ];
-#pragma unroll
-  for (int a = 0; a < NRB; ++a)
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) acc4[a][b] = 0.0;
-  constexpr int PA = KCS / 2, PB = KCS / (256 / NB);  // values per thread and chunk: A row t, B column q
-  const int t = tid & 127, ka = tid >> 7;
-  const int q = tid % NB, kb = tid / NB;
-  const bool ha = t < nrow, hb = q < w;
-  const double* pa = P + R0 + (ha ? t : 0);
-  const double* pb = I + (hb ? q : 0);
-  double ra[PA], rb[PB];
-  auto fetch = [&](int k0) {
-    const int kc = min(KCS, w - k0);
-#pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = pa[(int64_t)(k0 + min(ka + 2 * i, kc - 1)) * m];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = pb[(int64_t)(k0 + min(kb + (256 / NB) * i, kc - 1)) * w];
-  };
-  auto stage = [&](int k0) {
-    const int kc = min(KCS, w - k0);
-    const int kc4 = (kc + 3) & ~3;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int k = ka + 2 * i;
-      if (k < kc4) As[k * LDA + t] = (ha && k < kc) ? ra[i] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int k = kb + (256 / NB) * i;
-      if (k < kc4) Bs[k * LDB + q] = (hb && k < kc) ? rb[i] : 0.0;  // invL[j][k] -> Bs[k][j]
-    }
-  };
-  const int l15 = lane & 15, l3 = lane & 3, lk4 = lane >> 4;
-  const int prn = (nrow + 15) >> 4;      // 16-row groups that carry rows
-  const bool wave_on = 32 * wv < w;      // this wave's 32 columns exist
-  fetch(0);
-  for (int32_t k0 = 0; k0 < w; k0 += KCS) {
-    const int kc = min(KCS, w - k0);
-    const int kc4 = (kc + 3) & ~3;
-    if (k0 > 0) __syncthreads();  // the previous chunk has been consumed
-    stage(k0);
-    if (k0 + KCS < w) fetch(k0 + KCS);
-    __syncthreads();
-    if (wave_on) {
-      for (int k4 = 0; k4 < kc4; k4 += 4) {
-        double cv[NQ];
-#pragma unroll
-        for (int q4 = 0; q4 < NQ; ++q4) cv[q4] = Bs[(k4 + lk4) * LDB + 32 * wv + 4 * q4 + l3];
-#pragma unroll
-        for (int pr = 0; pr < NRB; ++pr)
-          if (pr < prn) {
-            const double rv = As[(k4 + lk4) * LDA + 16 * pr + l15];
-#pragma unroll
-            for (int q4 = 0; q4 < NQ; ++q4) acc4[pr][q4] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[q4], rv, acc4[pr][q4], 0, 0, 0);
-          }
-      }
-    }
-  }
-#pragma unroll
-  for (int pr = 0; pr < NRB; ++pr)
-#pragma unroll
-    for (int q4 = 0; q4 < NQ; ++q4) {
-      const int j = 32 * wv + 4 * q4 + lk4;
-      const int i = 16 * pr + l15;
-      if (i < nrow && R0 + i >= w && j < w) P[(int64_t)j * m + R0 + i] = acc4[pr][q4];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_dense_a: the dense-tail update with ONLY the B operand in LDS.  A wave multiplies its own 32 rows and nobody
