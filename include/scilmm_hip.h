@@ -169,7 +169,10 @@ int scilmm_logdet(scilmm_factor* fac, double* out);
 int scilmm_solve(scilmm_factor* fac, const double* B, int32_t r, double* X);
 /* (factor.L() @ R)[argsort(P)] : Z = P^T L R  (simulate_vector, SparseCholesky.py:50-51) */
 int scilmm_lmul(scilmm_factor* fac, const double* R, int32_t r, double* Z);
-/* factor.L() as CSC of the permuted factor (SparseCholesky.py:50); call with vals == NULL to get nnz. */
+/* factor.L() as CSC of the permuted factor (SparseCholesky.py:50); call with vals == NULL to get nnz.
+ * On a DISTRIBUTED factor (scilmm_dist_init with world > 1) it returns SCILMM_ERR_STATE with an explanatory message and leaves
+ * the factor untouched: a rank holds the prelude and its own tail panels only, and nothing on the hot path needs the gathered
+ * factor (simulate_vector goes through scilmm_lmul, which IS collective). */
 int scilmm_export_L(scilmm_factor* fac, int64_t* colptr, int32_t* rowidx, double* vals, int64_t* nnz);
 /* out[j] = sum_i (A_k U)_ij U_ij  (compute_gradients, SparseCholesky.py:65-66,70); U row-major n x r */
 int scilmm_quadforms(scilmm_symbolic* sym, int32_t k, const double* U, int32_t r, double* out);
@@ -185,6 +188,10 @@ int scilmm_spmm_dev(scilmm_symbolic* sym, int32_t k, const double* dX, int32_t r
  * second copy of the factor).  The handle is consumed: refactorize before the next solve.  scilmm_inverse_traces then
  * returns out[k] = tr(V^-1 A_k) = sum over A_k's pattern of Z_ij A_k,ij for every matrix k (one streaming pass each);
  * scilmm_export_L on an inverted handle returns the entries of Z on L's pattern.  No counterpart in the reference. */
+/* Single-GPU handles only: on a distributed factor both return SCILMM_ERR_STATE with an explanatory message before touching
+ * anything -- the factor stays valid and usable (the Takahashi recursion reads, for every front, the inverse entries of ALL
+ * later fronts: with rank-local storage that is a second fan-out in the opposite direction, not built).  The default
+ * Monte-Carlo trace of the reference needs neither. */
 int scilmm_selected_inverse(scilmm_factor* fac);
 int scilmm_inverse_traces(scilmm_factor* fac, double* out);
 

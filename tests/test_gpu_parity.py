@@ -621,6 +621,28 @@ def test_ibd_values_built_on_the_device_match_reference_goldens_bit_for_bit():
         sym.ibd_values_from_pedigree(0, par[::-1].copy())   # not in pedigree order
 
 
+def test_300k_values_against_cpu_port_digest():
+    """a VALUE-level check above 100k.  The BLAS-3 CPU port factorized the 300k probe workload once in the
+    build container (oracle/make_digest_300k.py, 7.6e13 flops, its own analysis with 512-column blocks) and left a digest:
+    log det V and, of V^-1 B for three seeded columns, every 997th row + column sums + column norms.  The HIP engine (its own
+    ordering and 128-column blocks) must reproduce them: log-det 1e-10, solution entries 1e-9 of the column's largest entry."""
+    import os
+    import bench
+    path = os.path.join(os.path.dirname(__file__), "golden", "D1_300k_cpu_port_digest.npz")
+    g = np.load(path)
+    A, C, y = bench.build_problem(str(g["workload"]), 0)
+    n = A.shape[0]
+    assert n == int(g["n"]) and A.nnz == int(g["nnz_A"]) and abs(float(A.data.sum()) - float(g["a_checksum"])) < 1e-6
+    sym = _engine([A, sp.identity(n, format="csr")])
+    f = sym.factorize([float(v) for v in g["sigma2"]])
+    assert abs(f.logdet() - float(g["logdet"])) < 1e-10 * abs(float(g["logdet"]))
+    B = np.random.default_rng(300).standard_normal((n, 3))
+    X = f(B)
+    scale = np.abs(X).max(axis=0)
+    assert np.all(np.abs(X[::int(g["stride"])] - g["X_rows"]).max(axis=0) < 1e-9 * scale)
+    assert rel_err(X.sum(axis=0), g["X_sum"]) < 1e-8 and rel_err(np.sqrt((X * X).sum(axis=0)), g["X_norm"]) < 1e-10
+
+
 def test_dominance_values_built_on_the_device_in_slot_order_bit_for_bit():
     """BASELINE configs[4]'s second variance component built where it is used (`scilmm_dominance_values_device`): from a
     value-less pattern (PatternCSR) and the parent table, A by the tabular recursion and D from A's resident slots.

@@ -52,6 +52,18 @@ def _worker(rank, world, port, out, env):
     rng = np.random.default_rng(0)
     B = rng.standard_normal((y.size, 7))
     X1 = eng.solve(B)
+    # what a distributed factor does NOT offer fails cleanly (SCILMM_ERR_STATE + message, include/scilmm_hip.h) and leaves the
+    # factor as it was: the gathered L, the selected inverse
+    from scilmm_amd._lib import ScilmmError
+    refused = 0
+    for call in (eng.fac.L, eng.fac.inverse_traces):
+        try:
+            call()
+        except ScilmmError as e:
+            refused += "distributed" in str(e)
+    assert refused == 2
+    eng.fac._s2 = np.array([0.45, 0.5])   # (inverse_traces forgets the sigma2 before it asks the library: nothing was consumed)
+    assert rel_err(eng.solve(B), X1) < 1e-14
     eng.factorize([0.3, 0.7])  # a second factorization on the same handle (stale panels must not survive)
     info = eng.sym.info()
     _, loff, params = tail_layout(eng.sym._h, info.nsuper, rank, world)
