@@ -365,11 +365,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    if world > 1 and "SCILMM_HOST_THREADS" not in os.environ and "OMP_NUM_THREADS" not in os.environ:
-        # the ranks of a node analyse the cohort at the same time: each gets its share of the CPUs this job may use
-        # (the library would otherwise size every rank's thread teams for all of them)
+    under_launcher = "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ
+    if "SCILMM_HOST_THREADS" not in os.environ and (under_launcher or "OMP_NUM_THREADS" not in os.environ):
+        # Host thread teams of the library (analysis, value permutation, device plan).  torch.distributed.run exports
+        # OMP_NUM_THREADS=1 to every worker unless the caller set it: a generic default of the launcher, not a choice about this
+        # job -- honoured, it would run the 20 s analysis of the 1M cohort on ONE thread (minutes).  So under a launcher the team
+        # size is always set here, from the CPUs this job may really use (affinity mask and cgroup quota): rank 0, which simulates
+        # and analyses the cohort while the others wait at a barrier, gets all of them, the others their share (they build their
+        # device plans at the same time).  A user's SCILMM_HOST_THREADS wins; without a launcher so does OMP_NUM_THREADS.
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        os.environ["SCILMM_HOST_THREADS"] = str(max(1, _effective_cpus() // max(1, local_world)))
+        cpus = _effective_cpus()
+        os.environ["SCILMM_HOST_THREADS"] = str(cpus if rank == 0 else max(1, cpus // max(1, local_world)))
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % ndev)  # one rank per GPU under the driver; the modulo only matters in rehearsals
     dev = torch.device("cuda", local_rank % ndev)
