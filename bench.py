@@ -411,7 +411,9 @@ def main():
             A = A[0]
     else:
         # (hand-off directory: memory-backed /dev/shm when it has the room -- 26 GB at the 1M config -- else the temp directory)
-        need = {"3m": 16e9, "1m": 6e9, "300k": 1e9}.get(args.workload, 0.5e9)  # (the pattern of A and the parent table: no values)
+        # (the pattern of A + the parent table -- no values -- and the image of the analysis the ranks share: 24 bytes per entry of
+        #  tril(A) for its assembly maps alone)
+        need = {"3m": 130e9, "1m": 45e9, "300k": 12e9}.get(args.workload, 3e9)
         import shutil
         import tempfile
         roots = [d for d in ("/dev/shm", os.environ.get("TMPDIR") or tempfile.gettempdir(), os.getcwd())
