@@ -53,3 +53,40 @@ def test_bad_arguments_are_rejected():
     sym = Symbolic([sp.identity(3, format="csr")], upload=False)
     with pytest.raises(ScilmmError):
         sym.release_host_maps()
+
+
+def test_round4_entry_points_validate_and_never_fall_back(gpu_available):
+    """The entry points added in round 4 reject bad arguments on the host and -- without a GPU -- fail with the device error
+    instead of computing anything on the CPU: `scilmm_csr_spmm_dev`, `scilmm_dominance_values_device`, the value-less
+    `PatternCSR` analysis, `scilmm_timing.n_late_split`."""
+    import ctypes as C
+    from scilmm_amd.factor import PatternCSR, Symbolic
+    L = _lib.lib()
+    vp = C.c_void_p
+    one = vp(8)   # (a non-null dummy: the argument checks come before any dereference)
+    assert L.scilmm_csr_spmm_dev(-1, one, one, one, one, 1, vp(16), None) == _lib.ERR_ARG
+    assert L.scilmm_csr_spmm_dev(4, one, one, one, one, 0, vp(16), None) == _lib.ERR_ARG      # r <= 0
+    assert L.scilmm_csr_spmm_dev(4, one, one, one, one, 3, one, None) == _lib.ERR_ARG         # X and Y alias
+    assert L.scilmm_csr_spmm_dev(4, None, one, one, one, 3, vp(16), None) == _lib.ERR_ARG
+    assert L.scilmm_csr_spmm_dev(0, one, None, None, one, 3, vp(16), None) == _lib.OK         # empty matrix: nothing to do
+    # a value-less pattern analyses like the matrix it came from
+    A = (sp.random(60, 60, density=0.1, random_state=3, format="csr") + sp.identity(60, format="csr")).tocsr()
+    A = (A + A.T).tocsr()
+    A.sort_indices()
+    P = PatternCSR(A.indptr, A.indices, 60)
+    I = sp.identity(60, format="csr")
+    sp_sym, sa_sym = Symbolic([P, I], upload=False), Symbolic([A, I], upload=False)
+    assert np.array_equal(sp_sym.P(), sa_sym.P()) and sp_sym.info().nnzL == sa_sym.info().nnzL
+    with pytest.raises(ValueError):
+        PatternCSR(A.indptr[:-1], A.indices, 60)
+    par = np.full((60, 2), -1, dtype=np.int32)
+    for bad in ((0, 0), (0, 5), (-1, 0), (1, 0)):   # k_dst == k_src, out of range, the diagonal-only identity as a target
+        assert L.scilmm_dominance_values_device(sp_sym._h, bad[0], bad[1], 60, _lib.ptr(par)) == _lib.ERR_ARG
+    assert L.scilmm_dominance_values_device(sp_sym._h, 0, 0, 59, _lib.ptr(par)) == _lib.ERR_ARG
+    assert "n_late_split" in dict(_lib.Timing._fields_)
+    if not gpu_available:
+        sym3 = Symbolic([P, P, I], upload=False)
+        with pytest.raises(_lib.ScilmmError, match="HIP|device"):
+            sym3.dominance_values_from(1, 0, par)            # needs the device: no CPU form exists
+        with pytest.raises(_lib.ScilmmError, match="HIP|device"):
+            sym3.ibd_values_from_pedigree(0, par)
