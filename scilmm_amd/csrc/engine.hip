@@ -132,6 +132,8 @@ struct Dev {
   int32_t tail_level = 0;               // level of the first tail front
   std::vector<uint8_t> outside_desc;    // [nsuper] descendant handled by k_outside
   OutsideWork* d_owork = nullptr;
+  int32_t* d_grp_next = nullptr;   // [nsuper] k_outside: next descendant with the same tail rows as this one, or -1
+  int32_t* d_grp_t0 = nullptr;     // [nsuper] its first tail row
   int64_t n_owork = 0;
   int32_t* d_tail_front = nullptr;
   uint8_t* d_keep_front = nullptr;
@@ -680,16 +682,62 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
       D->tail_level = S.sn_level[S.dense_first];
       const int32_t c0_tail = S.sn_start[S.dense_first];
       std::vector<OutsideWork> ow;
-      for (int32_t d = 0; d < S.dense_first; ++d) {
-        if (S.sn_level[d] >= D->tail_level) continue;  // finished too late for the one launch before the tail
-        const int32_t* rd = S.sn_rows.data() + S.sn_rowptr[d];
-        const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
-        const int32_t t0 = (int32_t)(std::lower_bound(rd, rd + md, c0_tail) - rd);
-        if (t0 >= md) continue;
-        D->outside_desc[d] = 1;
-        const int32_t nb = (md - t0 + TM - 1) / TM;
-        for (int32_t bi = 0; bi < nb; ++bi)
-          for (int32_t bj = 0; bj <= bi; ++bj) ow.push_back(OutsideWork{d, t0, bi, bj});
+      // descendants with IDENTICAL tail rows (the 128-column blocks of one wide supernode) form a group: one set of items for
+      // the group's leader, the kernel sums the members' products in its registers before the one atomic scatter
+      std::vector<int32_t> grp_next((size_t)std::max(S.nsuper, 1), -1), grp_t0((size_t)std::max(S.nsuper, 1), 0);
+      std::vector<int32_t> grp_width((size_t)std::max(S.nsuper, 1), 0);  // leader -> columns of the whole group
+      {
+        const char* egm = tune_env("SCILMM_OUTSIDE_MERGE");
+        const bool merge = !(egm && egm[0] == '0');
+        std::vector<std::pair<uint64_t, int32_t>> keyed;  // (hash of the tail rows, descendant)
+        for (int32_t d = 0; d < S.dense_first; ++d) {
+          if (S.sn_level[d] >= D->tail_level) continue;  // finished too late for the launches before the tail
+          const int32_t* rd = S.sn_rows.data() + S.sn_rowptr[d];
+          const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+          const int32_t t0 = (int32_t)(std::lower_bound(rd, rd + md, c0_tail) - rd);
+          if (t0 >= md) continue;
+          D->outside_desc[d] = 1;
+          grp_t0[(size_t)d] = t0;
+          uint64_t h = 1469598103934665603ull ^ (uint64_t)(md - t0);
+          for (int32_t t = t0; t < md; ++t) h = (h ^ (uint64_t)(uint32_t)rd[t]) * 1099511628211ull;
+          keyed.push_back({merge ? h : (uint64_t)d, d});
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint64_t, int32_t>& a, const std::pair<uint64_t, int32_t>& b) { return a.first < b.first; });
+        auto same_rows = [&](int32_t a, int32_t b) -> bool {
+          const int64_t na = S.sn_rowptr[a + 1] - S.sn_rowptr[a] - grp_t0[(size_t)a], nb = S.sn_rowptr[b + 1] - S.sn_rowptr[b] - grp_t0[(size_t)b];
+          return na == nb && std::memcmp(S.sn_rows.data() + S.sn_rowptr[a] + grp_t0[(size_t)a], S.sn_rows.data() + S.sn_rowptr[b] + grp_t0[(size_t)b],
+                                         sizeof(int32_t) * (size_t)na) == 0;
+        };
+        std::vector<int32_t> leaders;
+        for (size_t i = 0; i < keyed.size();) {
+          // members of one hash bucket, split into runs of truly identical row lists (a collision must not merge anything)
+          size_t j = i;
+          while (j < keyed.size() && keyed[j].first == keyed[i].first) ++j;
+          std::vector<uint8_t> used(j - i, 0);
+          for (size_t a = i; a < j; ++a) {
+            if (used[a - i]) continue;
+            const int32_t lead = keyed[a].second;
+            leaders.push_back(lead);
+            int32_t last = lead;
+            grp_width[(size_t)lead] = S.sn_start[lead + 1] - S.sn_start[lead];
+            for (size_t b = a + 1; b < j; ++b) {
+              if (used[b - i] || !merge || !same_rows(lead, keyed[b].second)) continue;
+              used[b - i] = 1;
+              grp_next[(size_t)last] = keyed[b].second;
+              last = keyed[b].second;
+              grp_width[(size_t)lead] += S.sn_start[last + 1] - S.sn_start[last];
+            }
+          }
+          i = j;
+        }
+        std::sort(leaders.begin(), leaders.end());
+        for (int32_t d : leaders) {
+          const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]), t0 = grp_t0[(size_t)d];
+          const int32_t nb = (md - t0 + TM - 1) / TM;
+          for (int32_t bi = 0; bi < nb; ++bi)
+            for (int32_t bj = 0; bj <= bi; ++bj) ow.push_back(OutsideWork{d, t0, bi, bj});
+        }
+        if (pverb) fprintf(stderr, "[scilmm plan] k_outside: %zu descendants in %zu groups of identical tail rows\n", keyed.size(), leaders.size());
       }
       D->n_owork = (int64_t)ow.size();
       if (D->n_owork == 0 || D->tail_level == 0) {
@@ -731,7 +779,7 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           std::vector<OutsideWork> sorted(ow.size());
           for (int32_t g = 0; g < nch; ++g) {
             std::stable_sort(ord.begin() + D->ochunk_ptr[g], ord.begin() + D->ochunk_ptr[g + 1], [&](size_t a, size_t b) {
-              return (S.sn_start[ow[a].d + 1] - S.sn_start[ow[a].d]) > (S.sn_start[ow[b].d + 1] - S.sn_start[ow[b].d]);
+              return grp_width[(size_t)ow[a].d] > grp_width[(size_t)ow[b].d];
             });
           }
           for (size_t i = 0; i < ord.size(); ++i) sorted[i] = ow[ord[i]];
@@ -752,6 +800,13 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         const OutsideWork* dow;
         if ((st = upload(sym, D, ow, &dow)) != SCILMM_OK) return st;
         D->d_owork = (OutsideWork*)dow;
+        {
+          const int32_t* dg;
+          if ((st = upload(sym, D, grp_next, &dg)) != SCILMM_OK) return st;
+          D->d_grp_next = (int32_t*)dg;
+          if ((st = upload(sym, D, grp_t0, &dg)) != SCILMM_OK) return st;
+          D->d_grp_t0 = (int32_t*)dg;
+        }
         const int32_t* dtf;
         if ((st = upload(sym, D, tf, &dtf)) != SCILMM_OK) return st;
         D->d_tail_front = (int32_t*)dtf;
@@ -2167,18 +2222,22 @@ int run_factorize(scilmm_factor* fac, const double* sigma2, int32_t* bad_col, bo
 #ifdef SCILMM_DIAG
         if (D->ablate == 6)  // timing ablations: no scatter / plain stores (WRONG numbers)
           hipLaunchKernelGGL((k_outside<true, 1>), dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
-                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, (const int32_t*)D->d_grp_next,
+                             (const int32_t*)D->d_grp_t0, fac->L);
         else if (D->ablate == 7)
           hipLaunchKernelGGL((k_outside<true, 2>), dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
-                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, (const int32_t*)D->d_grp_next,
+                             (const int32_t*)D->d_grp_t0, fac->L);
         else
 #endif
         if (D->use_mfma)
           hipLaunchKernelGGL(k_outside<true>, dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
-                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, (const int32_t*)D->d_grp_next,
+                             (const int32_t*)D->d_grp_t0, fac->L);
         else
           hipLaunchKernelGGL(k_outside<false>, dim3(cnt), dim3(256), 0, D->outside_st, D->v, S.dense_first, ow,
-                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, fac->L);
+                             (const int32_t*)D->d_tail_front, (const uint8_t*)D->d_keep_front, (const int32_t*)D->d_grp_next,
+                             (const int32_t*)D->d_grp_t0, fac->L);
         HIPCHK(hipGetLastError());
         launches++;
       }

@@ -1038,49 +1038,67 @@ template <bool MFMA, int SCATTER = 0>
 __global__ __launch_bounds__(256) void k_outside(DevSym S, int32_t dense_first, const OutsideWork* __restrict__ work,
                                                  const int32_t* __restrict__ tail_front,  // tail column (label - c0_tail) -> front
                                                  const uint8_t* __restrict__ keep_front,  // multi-GPU: fronts this rank computes
+                                                 const int32_t* __restrict__ grp_next,    // next descendant with the SAME tail rows, or -1
+                                                 const int32_t* __restrict__ grp_t0,      // its first tail row
                                                  double* __restrict__ L) {
   __shared__ __attribute__((aligned(16))) double As[KCS * LDA];  // [k][target-row entry]
   __shared__ __attribute__((aligned(16))) double Bs[KCS * LDB];  // [k][target-column entry]
   __shared__ int32_t lab_i[TM], lab_j[NB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const OutsideWork wk = work[blockIdx.x];
-  const int32_t d = wk.d;
-  const int32_t wd = S.sn_start[d + 1] - S.sn_start[d];
-  const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
-  const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
-  const double* Pd = L + S.sn_loff[d];
-  const int32_t ri0 = wk.t0 + TM * wk.bi, rj0 = wk.t0 + NB * wk.bj;  // first panel row of the two blocks
-  const int32_t ni = min(TM, md - ri0), nj = min(NB, md - rj0);
-  if (tid < TM) lab_i[tid] = tid < ni ? rd[ri0 + tid] : -1;
-  else if (tid < TM + NB) lab_j[tid - TM] = (tid - TM) < nj ? rd[rj0 + tid - TM] : -1;
+  int32_t ni, nj;
+  {
+    // the destination labels: the leader's tail rows (every member of its group has the very same ones)
+    const int32_t d = wk.d;
+    const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+    const int32_t* rd = S.sn_rows + S.sn_rowptr[d];
+    const int32_t ri0 = wk.t0 + TM * wk.bi, rj0 = wk.t0 + NB * wk.bj;  // first panel row of the two blocks
+    ni = min(TM, md - ri0);
+    nj = min(NB, md - rj0);
+    if (tid < TM) lab_i[tid] = tid < ni ? rd[ri0 + tid] : -1;
+    else if (tid < TM + NB) lab_j[tid - TM] = (tid - TM) < nj ? rd[rj0 + tid - TM] : -1;
+  }
   d4 acc[NJB][2];
 #pragma unroll
   for (int a = 0; a < NJB; ++a) { acc[a][0] = (d4){0.0, 0.0, 0.0, 0.0}; acc[a][1] = (d4){0.0, 0.0, 0.0, 0.0}; }
   // staging: thread (x = tid & 127, kk = tid >> 7) carries k = kk, kk + 2, ... of row x of both blocks
   const int x = tid & 127, kk = tid >> 7;
-  const double* pa = Pd + ri0 + min(x, ni - 1);
-  const double* pb = Pd + rj0 + min(x, nj - 1);
-  for (int32_t k0 = 0; k0 < wd; k0 += KCS) {
-    const int kc = min(KCS, wd - k0);
-    const int kc4 = (kc + 3) & ~3;
-    double va[KCS / 2], vb[KCS / 2];
+  bool first_chunk = true;
+  // (round 4) descendants with IDENTICAL tail rows -- the 128-column blocks a wide supernode was cut into -- hit the very same
+  // cells: their products are summed in the registers, K = the group's columns, and scattered ONCE (a quarter fewer atomic bytes
+  // at the 100k config: 61 549 -> 45 309 block pairs)
+  for (int32_t d = wk.d, t0 = wk.t0; d >= 0;) {
+    const int32_t wd = S.sn_start[d + 1] - S.sn_start[d];
+    const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]);
+    const double* Pd = L + S.sn_loff[d];
+    const int32_t ri0 = t0 + TM * wk.bi, rj0 = t0 + NB * wk.bj;
+    const double* pa = Pd + ri0 + min(x, ni - 1);
+    const double* pb = Pd + rj0 + min(x, nj - 1);
+    for (int32_t k0 = 0; k0 < wd; k0 += KCS) {
+      const int kc = min(KCS, wd - k0);
+      const int kc4 = (kc + 3) & ~3;
+      double va[KCS / 2], vb[KCS / 2];
 #pragma unroll
-    for (int i = 0; i < KCS / 2; ++i) {
-      const int64_t kq = k0 + min(kk + 2 * i, kc - 1);
-      va[i] = pa[kq * md];
-      vb[i] = pb[kq * md];
-    }
-    if (k0 > 0) __syncthreads();  // the previous chunk has been consumed
-#pragma unroll
-    for (int i = 0; i < KCS / 2; ++i) {
-      const int k = kk + 2 * i;
-      if (k < kc4) {
-        As[k * LDA + x] = (x < ni && k < kc) ? va[i] : 0.0;
-        Bs[k * LDB + x] = (x < nj && k < kc) ? vb[i] : 0.0;
+      for (int i = 0; i < KCS / 2; ++i) {
+        const int64_t kq = k0 + min(kk + 2 * i, kc - 1);
+        va[i] = pa[kq * md];
+        vb[i] = pb[kq * md];
       }
+      if (!first_chunk) __syncthreads();  // the previous chunk has been consumed
+      first_chunk = false;
+#pragma unroll
+      for (int i = 0; i < KCS / 2; ++i) {
+        const int k = kk + 2 * i;
+        if (k < kc4) {
+          As[k * LDA + x] = (x < ni && k < kc) ? va[i] : 0.0;
+          Bs[k * LDB + x] = (x < nj && k < kc) ? vb[i] : 0.0;
+        }
+      }
+      __syncthreads();
+      if (32 * wv < ni) tile_mma<MFMA>(As, Bs, kc4, NJB, lane, wv, acc);
     }
-    __syncthreads();
-    if (32 * wv < ni) tile_mma<MFMA>(As, Bs, kc4, NJB, lane, wv, acc);
+    d = grp_next[d];
+    if (d >= 0) t0 = grp_t0[d];
   }
   // scatter: acc[jb][ib][r] = U(i, j) with i = 32 wv + 16 ib + (lane & 15), j = 16 jb + (lane >> 4) + 4 r
   const int li = lane & 15, lr = lane >> 4;
