@@ -452,7 +452,7 @@ def main():
         sym_opts = {}
         for kv in filter(None, os.environ.get("SCILMM_BENCH_SYM", "").split(",")):
             k, v = kv.split("=")
-            sym_opts[k] = float(v) if "z" in k or "relax" == k[:5] and "." in v else int(v)
+            sym_opts[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
         sym = Symbolic([A] + (comps or []) + [sp.identity(n, format="csr")], **sym_opts)
     else:
         from scilmm_amd.dist import HipChainEngine
