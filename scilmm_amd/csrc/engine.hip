@@ -731,13 +731,35 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
           i = j;
         }
         std::sort(leaders.begin(), leaders.end());
+        // multi-GPU: a block pair adds into the panels of the columns of its block bj only; a rank keeps the pairs that reach
+        // a panel it owns (a 128-row block of a tall front spans a few panels: at 8 ranks most pairs are somebody else's --
+        // until round 4 every rank multiplied all of them and threw 7/8 of the products away in the epilogue)
+        const bool own_only = D->world > 1 && D->dist_first < S.nsuper;
+        int64_t pairs_all = 0;
         for (int32_t d : leaders) {
           const int32_t md = (int32_t)(S.sn_rowptr[d + 1] - S.sn_rowptr[d]), t0 = grp_t0[(size_t)d];
+          const int32_t* rd = S.sn_rows.data() + S.sn_rowptr[d];
           const int32_t nb = (md - t0 + TM - 1) / TM;
+          std::vector<uint8_t> col_mine((size_t)nb, 1);
+          if (own_only)
+            for (int32_t bj = 0; bj < nb; ++bj) {
+              // panels of the block's first and last column label (sorted rows: everything in between lies between them)
+              const int32_t r_lo = rd[t0 + NB * bj], r_hi = rd[std::min(md, t0 + NB * (bj + 1)) - 1];
+              int32_t f_lo = (int32_t)(std::upper_bound(S.sn_start.begin() + S.dense_first, S.sn_start.begin() + S.nsuper + 1, r_lo) - S.sn_start.begin()) - 1;
+              int32_t f_hi = (int32_t)(std::upper_bound(S.sn_start.begin() + S.dense_first, S.sn_start.begin() + S.nsuper + 1, r_hi) - S.sn_start.begin()) - 1;
+              uint8_t mine = 0;
+              for (int32_t f = f_lo; f <= f_hi && !mine; ++f) mine = D->keep_front[(size_t)f];
+              col_mine[(size_t)bj] = mine;
+            }
           for (int32_t bi = 0; bi < nb; ++bi)
-            for (int32_t bj = 0; bj <= bi; ++bj) ow.push_back(OutsideWork{d, t0, bi, bj});
+            for (int32_t bj = 0; bj <= bi; ++bj) {
+              ++pairs_all;
+              if (col_mine[(size_t)bj]) ow.push_back(OutsideWork{d, t0, bi, bj});
+            }
         }
-        if (pverb) fprintf(stderr, "[scilmm plan] k_outside: %zu descendants in %zu groups of identical tail rows\n", keyed.size(), leaders.size());
+        if (pverb)
+          fprintf(stderr, "[scilmm plan] k_outside: %zu descendants in %zu groups of identical tail rows; %lld of %lld block pairs reach a panel of this rank\n",
+                  keyed.size(), leaders.size(), (long long)ow.size(), (long long)pairs_all);
       }
       D->n_owork = (int64_t)ow.size();
       if (D->n_owork == 0 || D->tail_level == 0) {
