@@ -775,7 +775,8 @@ int ensure_device(scilmm_symbolic* sym, Dev** out) {
         };
         const char* ech = tune_env("SCILMM_OUTSIDE_CHUNKS");
         // (100k / 300k factorization, ms: 1 chunk 57.8 / 1357; 4 / 8 / 16 chunks on a low-priority stream 55.5 / 1344, - / 1339, 56.1 / 1335)
-        const int32_t want_chunks = std::max(1, ech ? atoi(ech) : 8);
+        // ... and the count follows the size: one chunk per ~16k block pairs, 4 .. 32 (1M: 2 / 8 / 32 chunks 26.64 / 26.63 / 26.51 s)
+        const int32_t want_chunks = std::max(1, ech ? atoi(ech) : (int32_t)std::min<int64_t>(32, std::max<int64_t>(4, (int64_t)ow.size() / 16384)));
         std::vector<int32_t> ffront(ow.size());
         for (size_t i = 0; i < ow.size(); ++i) ffront[i] = first_front(ow[i]);
         std::vector<size_t> ord(ow.size());
